@@ -1,0 +1,422 @@
+"""TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
+
+Golden-vector generator.  Runs ONLY in the build container: imports the reference from
+/root/reference on CPU (fp32), applies the harness-side patches listed in SURVEY.md section 8c
+(never edits the reference), and writes inputs + expected outputs to tests/golden/*.pt.
+The fixtures are data (tensors, floats); they load with torch.load(weights_only=True).
+
+    PYTHONDONTWRITEBYTECODE=1 python oracle/make_goldens.py
+
+Harness-side patches:
+  P1  StyleGan2GeneratorBlock.forward passes w_embs to to_rgb (shipped code omits it: stylegan2.py:64)
+  P2  every nn.LeakyReLU inside the discriminator gets inplace=False (progressive_gan.py:44 + :54 break autograd)
+  P3  base_dim chosen so that the first generator block is 512 channels (stylegan2.py:43-58,74)
+"""
+from __future__ import annotations
+
+import copy
+import os
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+sys.dont_write_bytecode = True
+sys.path.insert(0, REF)
+sys.path.insert(1, REPO)
+
+import torch  # noqa: E402
+from torch import nn  # noqa: E402
+
+import losses as ref_losses  # noqa: E402  (reference)
+import utils as ref_utils  # noqa: E402  (reference)
+from modelling import build_discriminator, build_generator  # noqa: E402  (reference)
+from modelling import nvidia_ops as ref_ops  # noqa: E402
+from modelling import progressive_gan as ref_pg  # noqa: E402
+from modelling import stylegan as ref_sg  # noqa: E402
+from modelling import stylegan2 as ref_sg2  # noqa: E402
+
+from oracle import gan_oracle as O  # noqa: E402
+from oracle.detparams import det_state, det_uniform, projections  # noqa: E402
+from oracle.tape import RandTape  # noqa: E402
+
+OUT = os.path.join(REPO, "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+
+
+# ---- P1 -------------------------------------------------------------------------------
+def _block_forward(self, x, w_embs):
+    for layer in self.layers:
+        x = layer(x, w_embs) if isinstance(layer, ref_sg2.ModulatedConv2d) else layer(x)
+    return x, self.to_rgb(x, w_embs)
+
+
+ref_sg2.StyleGan2GeneratorBlock.forward = _block_forward
+
+
+# ---- P2 -------------------------------------------------------------------------------
+def out_of_place(model: nn.Module) -> nn.Module:
+    for m in model.modules():
+        if isinstance(m, nn.LeakyReLU):
+            m.inplace = False
+    return model
+
+
+def save(name: str, obj) -> None:
+    path = os.path.join(OUT, name + ".pt")
+    torch.save(obj, path)
+    print(f"{name:28s} {os.path.getsize(path) / 1024:8.1f} KiB")
+
+
+def sd_of(m: nn.Module):
+    return {k: v.detach().clone() for k, v in m.state_dict().items()}
+
+
+def grads_of(loss, tensors):
+    gs = torch.autograd.grad(loss, tensors, allow_unused=True)
+    return [None if g is None else g.detach().clone() for g in gs]
+
+
+def named_grads(model: nn.Module):
+    return {k: (None if p.grad is None else p.grad.detach().clone()) for k, p in model.named_parameters()}
+
+
+# =========================================================================================
+def gold_modconv():
+    out = {}
+    for tag, k, demod in (("k3_demod", 3, True), ("k1_plain", 1, False)):
+        torch.manual_seed(11)
+        m = ref_sg2.ModulatedConv2d(16, 32, k, 128, demodulation=demod)
+        with torch.no_grad():
+            for p in m.parameters():
+                p.copy_(torch.randn_like(p) * (0.3 if p.ndim > 1 else 0.2))
+        x = torch.randn(4, 16, 8, 8, requires_grad=True)
+        w = torch.randn(4, 128, requires_grad=True)
+        params = dict(m.named_parameters())
+        leaves = [x, w] + list(params.values())
+        names = ["x", "w"] + list(params.keys())
+        y = m(x, w)
+        g1 = torch.autograd.grad(y.square().sum(), leaves, create_graph=True)
+        # double backward: differentiate |dL/dx|^2 + |dL/dw|^2 once more
+        second = g1[0].square().sum() + g1[1].square().sum()
+        g2 = torch.autograd.grad(second, leaves, allow_unused=True)
+        out[tag] = {
+            "state": sd_of(m),
+            "x": x.detach().clone(),
+            "w": w.detach().clone(),
+            "y": y.detach().clone(),
+            "grad": {n: g.detach().clone() for n, g in zip(names, g1)},
+            "grad2": {n: (None if g is None else g.detach().clone()) for n, g in zip(names, g2)},
+        }
+    save("modconv", out)
+
+
+def gold_upfirdn2d():
+    cases = []
+    torch.manual_seed(21)
+    specs = []
+    for ksz in range(2, 8):
+        kern = ref_ops.Blur.make_kernel(ksz)
+        p1 = (ksz - 1) // 2
+        p2 = ksz - 1 - p1
+        for up, down in ((1, 1), (2, 1), (1, 2)):
+            specs.append((kern, up, down, p1, p2, p1, p2))
+    r3 = torch.randn(3, 3)
+    specs += [
+        (r3, 1, 1, 1, 1, 1, 1),  # the microbench configuration (benchmark_upfirdn2d.py:60)
+        (r3, 2, 1, 1, 2, 1, 2),
+        (r3, 1, 2, 1, 2, 1, 2),
+        (r3, 1, 1, 2, 0, 0, 2),
+        (r3, 2, 2, 2, 1, 0, 3),
+        (torch.randn(4, 2), 2, 1, 0, 1, 2, 1),  # non-square taps
+        (torch.randn(4, 4), 1, 1, -1, 2, 2, -1),  # negative pad = crop
+        (torch.randn(2, 2), 3, 2, 1, 1, 0, 2),
+        (torch.ones(2, 2), 2, 1, 1, 0, 1, 0),  # nearest-up identity
+        (torch.ones(2, 2) / 4, 1, 2, 0, 0, 0, 0),  # avg-pool identity
+    ]
+    for kern, up, down, px1, px2, py1, py2 in specs:
+        x = torch.randn(2, 5, 8, 6, requires_grad=True)
+        args = (kern, up, down, px1, px2, py1, py2)
+        y_plain = ref_ops.upfirdn2d(x, *args)
+        (g1,) = torch.autograd.grad(y_plain.square().sum(), x, create_graph=True)
+        (g2,) = torch.autograd.grad(g1.square().sum(), x)
+        # The Function's backward (argument swap, nvidia_ops.py:53) only yields the right shape when
+        # p1 + p2 == k - 1 and the sizes divide; where it runs it must equal plain autograd.
+        fn_ok = True
+        try:
+            y = ref_ops.UpFIRDn2d.apply(x, *args)
+            assert torch.equal(y, y_plain)
+            (f1,) = torch.autograd.grad(y.square().sum(), x, create_graph=True)
+            (f2,) = torch.autograd.grad(f1.square().sum(), x)
+            assert torch.allclose(f1, g1, atol=1e-5) and torch.allclose(f2, g2, atol=1e-3, rtol=1e-4)
+        except RuntimeError:
+            fn_ok = False
+        y = y_plain
+        cases.append(
+            {
+                "kernel": kern.clone(),
+                "args": [up, down, px1, px2, py1, py2],
+                "x": x.detach().clone(),
+                "y": y.detach().clone(),
+                "g1": g1.detach().clone(),
+                "g2": g2.detach().clone(),
+                "function_backward_runs": fn_ok,
+            }
+        )
+    ident = {}
+    x = torch.randn(2, 3, 6, 4)
+    ident["x"] = x
+    ident["nearest_up2"] = nn.Upsample(scale_factor=2.0)(x)
+    ident["avg_pool2"] = nn.AvgPool2d(2)(x)
+    blur = {}
+    xb = torch.randn(2, 4, 8, 8)
+    blur["x"] = xb
+    for ksz, up, down in ((3, 1, 1), (4, 2, 1), (4, 1, 2), (2, 1, 1), (7, 1, 1)):
+        blur[f"k{ksz}_u{up}_d{down}"] = ref_ops.Blur(ksz, up, down)(xb)
+    save(
+        "upfirdn2d",
+        {
+            "cases": cases,
+            "make_kernel": {str(k): ref_ops.Blur.make_kernel(k) for k in range(2, 8)},
+            "identities": ident,
+            "blur": blur,
+        },
+    )
+
+
+def gold_small_ops():
+    torch.manual_seed(31)
+    out = {}
+    # Noise with recorded draw (stylegan.py:19-27)
+    noise_mod = ref_sg.Noise(6)
+    with torch.no_grad():
+        noise_mod.scale.copy_(torch.randn(6, 1, 1))
+    x = torch.randn(3, 6, 4, 4)
+    with RandTape() as tape:
+        y = noise_mod(x)
+    out["noise"] = {"x": x, "scale": noise_mod.scale.detach().clone(), "draw": tape.tape[0], "y": y.detach()}
+    # MinibatchStdDev fwd / grad / double-grad (progressive_gan.py:20-36)
+    x = torch.randn(8, 5, 4, 4, requires_grad=True)
+    y = ref_pg.MinibatchStdDev()(x)
+    wgt = torch.randn_like(y)
+    (g1,) = torch.autograd.grad((y * wgt).sum() + y[:, -1].square().sum(), x, create_graph=True)
+    (g2,) = torch.autograd.grad(g1.square().sum(), x)
+    out["mbstd"] = {"x": x.detach().clone(), "y": y.detach().clone(), "wgt": wgt, "g1": g1.detach().clone(), "g2": g2.detach().clone()}
+    # fused bias + leaky-relu: composition oracle
+    x = torch.randn(2, 6, 5, 5, requires_grad=True)
+    b = torch.randn(6, requires_grad=True)
+    y = nn.LeakyReLU(0.2)(x + b.view(1, -1, 1, 1))
+    gx, gb = torch.autograd.grad(y.square().sum(), [x, b], create_graph=True)
+    ggx, ggb = torch.autograd.grad(gx.square().sum() + gb.square().sum(), [x, b])
+    out["bias_lrelu"] = {
+        "x": x.detach().clone(),
+        "b": b.detach().clone(),
+        "y": y.detach().clone(),
+        "gx": gx.detach().clone(),
+        "gb": gb.detach().clone(),
+        "ggx": ggx.detach().clone(),
+        "ggb": ggb.detach().clone(),
+    }
+    # the five losses on fixed logits (losses.py:27-83)
+    d_r = torch.randn(8)
+    d_f = torch.randn(8)
+    lo = {"d_reals": d_r, "d_fakes": d_f}
+    for name in ("gan", "lsgan", "wgan", "hinge", "relativistic-gan"):
+        crit = ref_losses.get_loss(name)
+        lo[name] = [float(crit.d_loss(d_r, d_f)), float(crit.g_loss(d_f, lambda: d_r))]
+    out["losses"] = lo
+    # EMA after 0, 99, 100, 101, 103 steps (utils.py:75-99)
+    lin = nn.Linear(4, 3)
+    ema = ref_utils.EMA(lin, beta=0.999, warmup=100)
+    snaps = {"init": sd_of(lin)}
+    drift = torch.randn(3, 4) * 0.01
+    for step in range(1, 104):
+        with torch.no_grad():
+            lin.weight.add_(drift)
+            lin.bias.add_(0.001 * step)
+        ema.step()
+        if step in (1, 99, 100, 101, 103):
+            snaps[str(step)] = {"model": sd_of(lin), "ema": sd_of(ema.ema_model), "counter": int(ema.counter)}
+    snaps["drift"] = drift
+    out["ema"] = snaps
+    save("small_ops", out)
+
+
+def gold_disc():
+    torch.manual_seed(41)
+    out = {}
+    # one block (progressive_gan.py:40-54)
+    blk = out_of_place(ref_pg.ProgressiveGanDiscriminatorBlock(16, 32))
+    with torch.no_grad():
+        for p in blk.parameters():
+            p.copy_(torch.randn_like(p) * 0.2)
+    x = torch.randn(4, 16, 8, 8, requires_grad=True)
+    y = blk(x)
+    leaves = [x] + list(blk.parameters())
+    names = ["x"] + [k for k, _ in blk.named_parameters()]
+    g1 = torch.autograd.grad(y.square().sum(), leaves, create_graph=True)
+    g2 = torch.autograd.grad(g1[0].square().sum(), leaves, allow_unused=True)
+    out["block"] = {
+        "state": sd_of(blk),
+        "x": x.detach().clone(),
+        "y": y.detach().clone(),
+        "grad": {n: g.detach().clone() for n, g in zip(names, g1)},
+        "grad2": {n: (None if g is None else g.detach().clone()) for n, g in zip(names, g2)},
+    }
+    # tiny full discriminator: hinge, R1, WGAN-GP (losses.py:64-69,89-103)
+    disc = out_of_place(build_discriminator("stylegan2", img_size=16, base_dim=8))
+    with torch.no_grad():
+        for k, p in disc.named_parameters():
+            if k.endswith("scale"):
+                p.copy_(0.5 + torch.rand_like(p))  # 1e-4 would hide the residual branch
+            elif k.endswith("bias"):
+                p.copy_(torch.randn_like(p) * 0.1)
+    reals = torch.randn(8, 3, 16, 16)
+    fakes = torch.randn(8, 3, 16, 16)
+    rec = {"state": sd_of(disc), "reals": reals.clone(), "fakes": fakes.clone()}
+    rec["logits_reals"] = disc(reals).detach().clone()
+
+    disc.zero_grad()
+    hinge = ref_losses.HingeLoss.d_loss(disc(reals), disc(fakes))
+    hinge.backward()
+    rec["hinge"] = {"value": float(hinge), "grads": named_grads(disc)}
+
+    disc.zero_grad()
+    r = reals.clone().requires_grad_()
+    d_r = disc(r)
+    r1 = ref_losses.r1_regularizer(disc, r, fakes, d_r)
+    r1.backward()
+    rec["r1"] = {"value": float(r1), "grads": named_grads(disc), "grad_reals": r.grad.detach().clone()}
+
+    disc.zero_grad()
+    r = reals.clone().requires_grad_()
+    d_r = disc(r)
+    d_f = disc(fakes)
+    total = ref_losses.HingeLoss.d_loss(d_r, d_f) + ref_losses.r1_regularizer(disc, r, fakes, d_r)
+    total.backward()
+    rec["hinge_r1"] = {"value": float(total), "grads": named_grads(disc)}
+
+    disc.zero_grad()
+    with RandTape() as tape:
+        gp = ref_losses.wgan_gp_regularizer(disc, reals, fakes, None)
+    gp.backward()
+    rec["wgan_gp"] = {"value": float(gp), "alpha": tape.tape[0], "grads": named_grads(disc)}
+    out["disc16"] = rec
+    save("disc", out)
+
+
+def gold_generator():
+    """StyleGan2Generator(16, base_dim=128): smallest size whose first block is 512-ch (P3).
+    4.6 M parameters -> built from oracle.detparams (seed 5), big grads stored as projections."""
+    gen = build_generator("stylegan2", img_size=16, base_dim=128)
+    shapes = {k: tuple(v.shape) for k, v in gen.state_dict().items()}
+    assert shapes == O.stylegan2_generator_shapes(16, base_dim=128), "shape table drifted from the reference"
+    gen.load_state_dict(det_state(shapes, seed=5))
+    z = det_uniform((4, 128), 901) * 3.0
+    with RandTape() as tape:
+        img = gen(z)
+    loss = (img * det_uniform(tuple(img.shape), 902)).sum() + img.square().mean()
+    loss.backward()
+    grads = {}
+    for k, p in gen.named_parameters():
+        grads[k] = p.grad.detach().clone() if p.numel() <= 4096 else projections(p.grad)
+    save(
+        "generator16",
+        {"seed": 5, "img_size": 16, "base_dim": 128, "z": z, "noise": tape.tape, "img": img.detach().clone(), "loss": float(loss), "grads": grads},
+    )
+
+
+def gold_dcgan():
+    torch.manual_seed(61)
+    disc = build_discriminator("dcgan", img_size=64, base_dim=8, norm="none")
+    gen = build_generator("dcgan", img_size=64, base_dim=8)
+    with torch.no_grad():
+        for net in (disc, gen):
+            for p in net.parameters():
+                if p.ndim > 1:
+                    p.mul_(5.0)  # N(0, 0.02) leaves everything ~0; widen so grads are informative
+                else:
+                    p.add_(torch.randn_like(p) * 0.1)
+    z = torch.randn(4, 128)
+    reals = torch.randn(4, 3, 64, 64)
+    fakes = gen(z)
+    rec = {"d_state": sd_of(disc), "g_state": sd_of(gen), "z": z, "reals": reals, "fakes": fakes.detach().clone()}
+    rec["logits_reals"] = disc(reals).detach().clone()
+    disc.zero_grad()
+    with RandTape() as tape:
+        gp = ref_losses.wgan_gp_regularizer(disc, reals, fakes.detach(), None)
+    loss = ref_losses.WganLoss.d_loss(disc(reals), disc(fakes.detach())) + gp
+    loss.backward()
+    rec["wgan_gp"] = {"value": float(gp), "loss": float(loss), "alpha": tape.tape[0], "grads": named_grads(disc)}
+    gen.zero_grad()
+    gl = ref_losses.WganLoss.g_loss(disc(gen(z)), None)
+    gl.backward()
+    rec["g_loss"] = {"value": float(gl), "grads": named_grads(gen)}
+    save("dcgan", rec)
+
+
+def gold_trajectory():
+    """10 generator iterations of the train_celeba.py:111-149 loop body (hinge + R1, n_disc=1, grad_accum=1,
+    fp32, no autocast) on reference modules/losses/EMA; 16x16, batch 4, Adam(2e-4, betas (0.0, 0.9)).
+    The loop body is restated here from the reference by reading (train_celeba.py itself needs wandb /
+    torchvision / CelebA download and cannot be imported)."""
+    gen = build_generator("stylegan2", img_size=16, base_dim=128)
+    disc = out_of_place(build_discriminator("stylegan2", img_size=16, base_dim=16))
+    g_shapes = {k: tuple(v.shape) for k, v in gen.state_dict().items()}
+    d_shapes = {k: tuple(v.shape) for k, v in disc.state_dict().items()}
+    assert d_shapes == O.stylegan2_discriminator_shapes(16, base_dim=16)
+    gen.load_state_dict(det_state(g_shapes, seed=9, bias_amp=0.0, scale_amp=0.05))
+    disc.load_state_dict(det_state(d_shapes, seed=10, bias_amp=0.0, scale_amp=0.5))
+    ema = ref_utils.EMA(gen, warmup=3)
+    optim_d = torch.optim.Adam(disc.parameters(), 2e-4, betas=(0.0, 0.9))
+    optim_g = torch.optim.Adam(gen.parameters(), 2e-4, betas=(0.0, 0.9))
+    criterion = ref_losses.get_loss("hinge")
+    regularizer = ref_losses.get_regularizer("r1")
+    steps = []
+    reals_all = []
+    tape_all = []
+    for step in range(10):
+        reals = det_uniform((4, 3, 16, 16), 1000 + step) * 2.0
+        reals_all.append(reals.clone())
+        with RandTape() as tape:
+            cached = reals.clone()
+            reals.requires_grad_()
+            zs = torch.randn(reals.shape[0], 128)
+            with torch.no_grad():
+                fakes = gen(zs)
+            d_reals = disc(reals)
+            d_fakes = disc(fakes)
+            loss_d = criterion.d_loss(d_reals, d_fakes)
+            loss_d = loss_d + regularizer(disc, reals, fakes, d_reals)
+            loss_d.backward()
+            optim_d.step()
+            optim_d.zero_grad()
+            disc.requires_grad_(False)
+            zs = torch.randn(reals.shape[0], 128)
+            loss_g = criterion.g_loss(disc(gen(zs)), lambda: disc(cached))
+            loss_g.backward()
+            optim_g.step()
+            optim_g.zero_grad()
+            disc.requires_grad_(True)
+            ema.step()
+        tape_all.append(tape.tape)
+        steps.append([float(loss_d), float(loss_g), float(d_reals.mean()), float(d_fakes.mean())])
+    final = {
+        "gen": {k: projections(v) for k, v in gen.state_dict().items()},
+        "disc": {k: projections(v) for k, v in disc.state_dict().items()},
+        "ema": {k: projections(v) for k, v in ema.ema_model.state_dict().items()},
+    }
+    save(
+        "trajectory16",
+        {"gen_seed": 9, "disc_seed": 10, "ema_warmup": 3, "reals_salt0": 1000, "tape": tape_all, "steps": torch.tensor(steps, dtype=torch.float64), "final": final},
+    )
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    gold_modconv()
+    gold_upfirdn2d()
+    gold_small_ops()
+    gold_disc()
+    gold_generator()
+    gold_dcgan()
+    gold_trajectory()
