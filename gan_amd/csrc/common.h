@@ -1,0 +1,95 @@
+// Shared helpers for the gfx950 kernels of libgan_amd.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/gan_amd.h"
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+// ---- error plumbing ---------------------------------------------------------------------
+void gan_set_error(const char* fmt, ...);
+
+#define GAN_CHECK_ARG(cond, ...)  \
+    do {                          \
+        if (!(cond)) {            \
+            gan_set_error(__VA_ARGS__); \
+            return GAN_ERR_ARG;   \
+        }                         \
+    } while (0)
+
+#define GAN_CHECK_LAUNCH(name)                                                   \
+    do {                                                                         \
+        hipError_t e_ = hipGetLastError();                                       \
+        if (e_ != hipSuccess) {                                                  \
+            gan_set_error("%s: launch failed: %s", name, hipGetErrorString(e_)); \
+            return GAN_ERR_LAUNCH;                                               \
+        }                                                                        \
+    } while (0)
+
+// ---- 16-byte vector access: V elements of T as floats ------------------------------------
+template <typename T>
+struct VecOf;
+template <>
+struct VecOf<float> {
+    static constexpr int V = 4;
+};
+template <>
+struct VecOf<bf16> {
+    static constexpr int V = 8;
+};
+
+template <typename T, int V>
+__device__ __forceinline__ void load_f(const T* p, float (&out)[V]);
+
+template <>
+__device__ __forceinline__ void load_f<float, 4>(const float* p, float (&out)[4]) {
+    const float4 v = *reinterpret_cast<const float4*>(p);
+    out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+}
+template <>
+__device__ __forceinline__ void load_f<float, 1>(const float* p, float (&out)[1]) {
+    out[0] = *p;
+}
+template <>
+__device__ __forceinline__ void load_f<bf16, 8>(const bf16* p, float (&out)[8]) {
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) out[i] = (float)v[i];
+}
+template <>
+__device__ __forceinline__ void load_f<bf16, 1>(const bf16* p, float (&out)[1]) {
+    out[0] = (float)*p;
+}
+
+template <typename T, int V>
+__device__ __forceinline__ void store_f(T* p, const float (&in)[V]);
+
+template <>
+__device__ __forceinline__ void store_f<float, 4>(float* p, const float (&in)[4]) {
+    *reinterpret_cast<float4*>(p) = make_float4(in[0], in[1], in[2], in[3]);
+}
+template <>
+__device__ __forceinline__ void store_f<float, 1>(float* p, const float (&in)[1]) {
+    *p = in[0];
+}
+template <>
+__device__ __forceinline__ void store_f<bf16, 8>(bf16* p, const float (&in)[8]) {
+    bf16x8 v;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (bf16)in[i];
+    *reinterpret_cast<bf16x8*>(p) = v;
+}
+template <>
+__device__ __forceinline__ void store_f<bf16, 1>(bf16* p, const float (&in)[1]) {
+    *p = (bf16)in[0];
+}
+
+__device__ __forceinline__ float lrelu_f(float v, float slope) { return v > 0.f ? v : v * slope; }
+__device__ __forceinline__ float lrelu_mask(float y, float slope) { return y > 0.f ? 1.f : slope; }
+
+static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -1,0 +1,346 @@
+// Implicit-GEMM convolution on MFMA (gfx950), channels-last, stride 1.
+//
+//   GEMM view:  M = N*Ho*Wo output pixels,  N = Cout,  K = kh*kw*Cin  (k = tap*Cin + ci)
+//   A[m][k]  = X[n, oy+dy-py, ox+dx-px, ci] * in_scale[n][ci]      gathered on the fly (zero outside)
+//   B[co][k] = Wt[co][k]                                           K-contiguous weights
+//   D[m][co] = act(out_scale[n][co] * sum_k A*B + bias[co] + noise[m]*noise_scale[co])
+//
+// One workgroup = 4 waves = a BM x BN tile of D.  Per 32-deep K step both operand tiles are
+// staged global -> registers -> LDS (double-buffered LDS, one barrier per step, next step's
+// global loads issued before the current step's MFMAs) and consumed as 16x16x32 bf16 MFMA
+// fragments (fp32: eight 16x16x4 fp32 MFMAs per fragment, exact fp32 products).  Each lane's
+// fragment is 8 consecutive k of one row, so an LDS row (32 k) is read with one 16-byte
+// ds_read per lane; rows are XOR-swizzled at 16-byte granularity to spread the four k-chunks
+// of a 16-row fragment over all LDS banks.
+#include "common.h"
+
+namespace {
+
+struct ConvArgs {
+    const void* x;
+    const void* wt;
+    void* y;
+    const float* in_scale;
+    const float* out_scale;
+    const float* bias;
+    const void* noise;
+    const float* noise_scale;
+    float slope;
+    int N, H, W, Cin;  // physical input
+    int Hl, Wl;        // logical input (2H, 2W when up2)
+    int up2;
+    int Ho, Wo, Cout;
+    int kh, kw, py, px;
+    int Kpad, ksteps;
+    int64_t M;
+};
+
+template <typename T>
+struct Mma;
+
+template <>
+struct Mma<bf16> {
+    typedef bf16x8 Frag;
+    static __device__ __forceinline__ Frag load(const char* p) { return *reinterpret_cast<const bf16x8*>(p); }
+    static __device__ __forceinline__ void mma(const Frag& a, const Frag& b, f32x4& c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+};
+
+template <>
+struct Mma<float> {
+    struct Frag {
+        float4 lo, hi;
+    };
+    static __device__ __forceinline__ Frag load(const char* p) {
+        Frag f;
+        f.lo = *reinterpret_cast<const float4*>(p);
+        f.hi = *reinterpret_cast<const float4*>(p + 16);
+        return f;
+    }
+    // Lane group q = lane>>4 holds k = 8q..8q+7 of the 32-deep step; MFMA j sums element j of
+    // the four groups.  A and B use the same assignment, so the k order is immaterial.
+    static __device__ __forceinline__ void mma(const Frag& a, const Frag& b, f32x4& c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.lo.x, b.lo.x, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.lo.y, b.lo.y, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.lo.z, b.lo.z, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.lo.w, b.lo.w, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.hi.x, b.hi.x, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.hi.y, b.hi.y, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.hi.z, b.hi.z, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.hi.w, b.hi.w, c, 0, 0, 0);
+    }
+};
+
+// byte offset of 16-byte chunk `ch` of LDS row `row`
+template <typename T>
+__device__ __forceinline__ int lds_off(int row, int ch);
+template <>
+__device__ __forceinline__ int lds_off<bf16>(int row, int ch) {
+    return row * 64 + ((ch ^ ((-(row >> 2)) & 3)) << 4);
+}
+template <>
+__device__ __forceinline__ int lds_off<float>(int row, int ch) {
+    // keep the two chunks of a lane's 32-byte fragment adjacent; rotate chunk pairs by row
+    return row * 128 + ((((ch >> 1) ^ ((row >> 1) & 3)) << 5) | ((ch & 1) << 4));
+}
+
+__device__ __forceinline__ uint4 scale_chunk(uint4 raw, const float* s, bf16) {
+    bf16x8 v = *reinterpret_cast<bf16x8*>(&raw);
+    const float4 s0 = *reinterpret_cast<const float4*>(s);
+    const float4 s1 = *reinterpret_cast<const float4*>(s + 4);
+    v[0] = (bf16)((float)v[0] * s0.x);
+    v[1] = (bf16)((float)v[1] * s0.y);
+    v[2] = (bf16)((float)v[2] * s0.z);
+    v[3] = (bf16)((float)v[3] * s0.w);
+    v[4] = (bf16)((float)v[4] * s1.x);
+    v[5] = (bf16)((float)v[5] * s1.y);
+    v[6] = (bf16)((float)v[6] * s1.z);
+    v[7] = (bf16)((float)v[7] * s1.w);
+    return *reinterpret_cast<uint4*>(&v);
+}
+__device__ __forceinline__ uint4 scale_chunk(uint4 raw, const float* s, float) {
+    float4 v = *reinterpret_cast<float4*>(&raw);
+    const float4 s0 = *reinterpret_cast<const float4*>(s);
+    v.x *= s0.x;
+    v.y *= s0.y;
+    v.z *= s0.z;
+    v.w *= s0.w;
+    return *reinterpret_cast<uint4*>(&v);
+}
+
+template <typename T, int BM, int BN, int WM, int WN>
+__global__ void __launch_bounds__(256) conv_fwd_k(const ConvArgs p) {
+    constexpr int ROWB = 32 * (int)sizeof(T);  // bytes per LDS row (32 k)
+    constexpr int CH = ROWB / 16;               // 16-byte chunks per row
+    constexpr int EPC = 16 / (int)sizeof(T);    // elements per chunk
+    constexpr int NA = (BM * CH + 255) / 256;   // A chunks staged per thread
+    constexpr int NB = (BN * CH + 255) / 256;
+    constexpr int TM = BM / WM, TN = BN / WN;
+    constexpr int FM = TM / 16, FN = TN / 16;
+    constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB;
+    typedef typename Mma<T>::Frag Frag;
+
+    __shared__ __attribute__((aligned(16))) char lds[2 * (A_BYTES + B_BYTES)];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = tid >> 6;
+    const int wm = wid / WN, wn = wid % WN;
+    const int64_t bm0 = (int64_t)blockIdx.x * BM;
+    const int bn0 = blockIdx.y * BN;
+
+    const T* __restrict__ x = (const T*)p.x;
+    const T* __restrict__ wt = (const T*)p.wt;
+    const int HoWo = p.Ho * p.Wo;
+    const int ntaps = p.kh * p.kw;
+
+    // ---- per-thread staging bookkeeping -------------------------------------------------
+    const int ch = tid % CH;  // same chunk column for every row this thread stages
+    int a_n[NA], a_oy[NA], a_ox[NA];
+    bool a_ok[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int row = (tid + i * 256) / CH;
+        const int64_t m = bm0 + row;
+        a_ok[i] = (row < BM) && (m < p.M);
+        const int64_t mm = a_ok[i] ? m : 0;
+        const int n = (int)(mm / HoWo);
+        const int rem = (int)(mm - (int64_t)n * HoWo);
+        a_n[i] = n;
+        a_oy[i] = rem / p.Wo;
+        a_ox[i] = rem - a_oy[i] * p.Wo;
+    }
+    // running (tap, ci) of this thread's chunk; advances by 32 elements per K step
+    int kelem = ch * EPC;
+    int tap = kelem / p.Cin;
+    int ci = kelem - tap * p.Cin;
+    int dy = tap / p.kw;
+    int dx = tap - dy * p.kw;
+
+    uint4 a_reg[NA], b_reg[NB];
+
+    auto load_step = [&](int s) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int iy = a_oy[i] + dy - p.py;
+            const int ix = a_ox[i] + dx - p.px;
+            const bool ok = a_ok[i] && tap < ntaps && (unsigned)iy < (unsigned)p.Hl && (unsigned)ix < (unsigned)p.Wl;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (ok) {
+                const int64_t off = (((int64_t)a_n[i] * p.H + (iy >> p.up2)) * p.W + (ix >> p.up2)) * p.Cin + ci;
+                v = *reinterpret_cast<const uint4*>(x + off);
+                if (p.in_scale) v = scale_chunk(v, p.in_scale + (int64_t)a_n[i] * p.Cin + ci, T());
+            }
+            a_reg[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int row = (tid + i * 256) / CH;
+            const int co = bn0 + row;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (row < BN && co < p.Cout)
+                v = *reinterpret_cast<const uint4*>(wt + (int64_t)co * p.Kpad + (int64_t)s * 32 + ch * EPC);
+            b_reg[i] = v;
+        }
+        // advance the k tracker to the next step
+        ci += 32;
+        while (ci >= p.Cin) {
+            ci -= p.Cin;
+            ++tap;
+            if (++dx == p.kw) {
+                dx = 0;
+                ++dy;
+            }
+        }
+    };
+
+    auto store_step = [&](int buf) {
+        char* A = lds + buf * (A_BYTES + B_BYTES);
+        char* B = A + A_BYTES;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int row = (tid + i * 256) / CH;
+            if (row < BM) *reinterpret_cast<uint4*>(A + lds_off<T>(row, ch)) = a_reg[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int row = (tid + i * 256) / CH;
+            if (row < BN) *reinterpret_cast<uint4*>(B + lds_off<T>(row, ch)) = b_reg[i];
+        }
+    };
+
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int frow = lane & 15;
+    const int fq = lane >> 4;
+    constexpr int CPF = (int)sizeof(Frag) / 16;  // chunks per fragment (1 bf16, 2 fp32)
+
+    load_step(0);
+    store_step(0);
+    __syncthreads();
+
+    for (int s = 0; s < p.ksteps; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < p.ksteps) load_step(s + 1);
+
+        const char* A = lds + buf * (A_BYTES + B_BYTES);
+        const char* B = A + A_BYTES;
+        Frag af[FM], bf[FN];
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            const int row = wm * TM + i * 16 + frow;
+            af[i] = Mma<T>::load(A + lds_off<T>(row, fq * CPF));
+        }
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            const int row = wn * TN + j * 16 + frow;
+            bf[j] = Mma<T>::load(B + lds_off<T>(row, fq * CPF));
+        }
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) Mma<T>::mma(af[i], bf[j], acc[i][j]);
+
+        if (s + 1 < p.ksteps) store_step(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: D layout col = lane&15 (co), row = (lane>>4)*4 + r (pixel) -------------
+    T* __restrict__ y = (T*)p.y;
+    const T* __restrict__ noise = (const T*)p.noise;
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t m = bm0 + wm * TM + i * 16 + fq * 4 + r;
+            if (m >= p.M) continue;
+            const int n = (int)(m / HoWo);
+            const float nz = noise ? (float)noise[m] : 0.f;
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const int co = bn0 + wn * TN + j * 16 + frow;
+                if (co >= p.Cout) continue;
+                float v = acc[i][j][r];
+                if (p.out_scale) v *= p.out_scale[(int64_t)n * p.Cout + co];
+                if (p.bias) v += p.bias[co];
+                if (noise) v = fmaf(nz, p.noise_scale[co], v);
+                v = lrelu_f(v, p.slope);
+                y[m * p.Cout + co] = (T)v;
+            }
+        }
+    }
+}
+
+template <typename T, int BM, int BN, int WM, int WN>
+int launch_cfg(const ConvArgs& a, hipStream_t st) {
+    const int64_t gm = ceil_div64(a.M, BM);
+    const int gn = (a.Cout + BN - 1) / BN;
+    if (gm >= (1LL << 31) || gn > 65535) {
+        gan_set_error("conv2d_fwd: grid too large");
+        return GAN_ERR_ARG;
+    }
+    hipLaunchKernelGGL((conv_fwd_k<T, BM, BN, WM, WN>), dim3((unsigned)gm, (unsigned)gn), dim3(256), 0, st, a);
+    GAN_CHECK_LAUNCH("conv2d_fwd");
+    return GAN_OK;
+}
+
+template <typename T>
+int launch(const ConvArgs& a, hipStream_t st) {
+    if constexpr (sizeof(T) == 4) {
+        // fp32 tiles are twice the bytes: keep 2 x (BM + BN) x 128 B within 64 KiB of LDS
+        if (a.Cout <= 16) return launch_cfg<T, 128, 16, 4, 1>(a, st);
+        if (a.Cout <= 32) return launch_cfg<T, 128, 32, 4, 1>(a, st);
+        if (a.M >= 64 * 1024) return launch_cfg<T, 128, 64, 2, 2>(a, st);
+        return launch_cfg<T, 64, 64, 2, 2>(a, st);
+    } else {
+        if (a.Cout <= 16) return launch_cfg<T, 256, 16, 4, 1>(a, st);
+        if (a.Cout <= 32) return launch_cfg<T, 256, 32, 4, 1>(a, st);
+        if (a.Cout <= 64) {
+            if (a.M >= 64 * 1024) return launch_cfg<T, 128, 64, 2, 2>(a, st);
+            return launch_cfg<T, 64, 64, 2, 2>(a, st);
+        }
+        const int64_t big_blocks = ceil_div64(a.M, 128) * ((a.Cout + 127) / 128);
+        if (big_blocks >= 512) return launch_cfg<T, 128, 128, 2, 2>(a, st);
+        return launch_cfg<T, 64, 64, 2, 2>(a, st);
+    }
+}
+
+}  // namespace
+
+extern "C" int gan_conv2d_fwd(const void* x, const void* wt, void* y, const float* in_scale, const float* out_scale,
+                              const float* bias, const void* noise, const float* noise_scale, float slope, int N,
+                              int H, int W, int Cin, int up2, int Ho, int Wo, int Cout, int kh, int kw, int py, int px,
+                              int Kpad, int dtype, gan_stream_t stream) {
+    GAN_CHECK_ARG(N == 0 || (x && wt && y), "conv2d_fwd: null pointer");
+    GAN_CHECK_ARG(dtype == GAN_F32 || dtype == GAN_BF16, "conv2d_fwd: bad dtype %d", dtype);
+    GAN_CHECK_ARG(N >= 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Ho > 0 && Wo > 0, "conv2d_fwd: bad shape");
+    GAN_CHECK_ARG(Cin % 8 == 0, "conv2d_fwd: Cin=%d must be a multiple of 8 (pad the input)", Cin);
+    GAN_CHECK_ARG(kh >= 1 && kw >= 1 && kh * kw <= 64, "conv2d_fwd: bad kernel %dx%d", kh, kw);
+    GAN_CHECK_ARG(up2 == 0 || up2 == 1, "conv2d_fwd: up2 must be 0 or 1");
+    GAN_CHECK_ARG(Kpad % 32 == 0 && Kpad >= kh * kw * Cin, "conv2d_fwd: Kpad=%d must be a multiple of 32 and >= %d",
+                  Kpad, kh * kw * Cin);
+    GAN_CHECK_ARG((noise == nullptr) == (noise_scale == nullptr), "conv2d_fwd: noise and noise_scale go together");
+    const int Hl = up2 ? 2 * H : H, Wl = up2 ? 2 * W : W;
+    GAN_CHECK_ARG(Ho == Hl + 2 * py - kh + 1 && Wo == Wl + 2 * px - kw + 1,
+                  "conv2d_fwd: output %dx%d does not match input %dx%d, kernel %dx%d, pad %d,%d", Ho, Wo, Hl, Wl, kh,
+                  kw, py, px);
+    GAN_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)wt % 16) == 0, "conv2d_fwd: x and wt must be 16-byte aligned");
+    if (N == 0) return GAN_OK;
+    ConvArgs a;
+    a.x = x; a.wt = wt; a.y = y;
+    a.in_scale = in_scale; a.out_scale = out_scale; a.bias = bias;
+    a.noise = noise; a.noise_scale = noise_scale; a.slope = slope;
+    a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Hl = Hl; a.Wl = Wl; a.up2 = up2;
+    a.Ho = Ho; a.Wo = Wo; a.Cout = Cout; a.kh = kh; a.kw = kw; a.py = py; a.px = px;
+    a.Kpad = Kpad;
+    a.ksteps = (kh * kw * Cin + 31) / 32;
+    a.M = (int64_t)N * Ho * Wo;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == GAN_F32) return launch<float>(a, st);
+    return launch<bf16>(a, st);
+}

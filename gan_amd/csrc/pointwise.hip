@@ -1,0 +1,442 @@
+// HBM-streaming channels-last kernels: upfirdn2d, fused affine/noise/residual/leaky-ReLU,
+// its backward building block, channel reductions, MinibatchStdDev statistic, EMA lerp.
+// Every thread moves 16 bytes per access (8 bf16 / 4 fp32) when C allows, scalar otherwise.
+#include "common.h"
+
+static constexpr int TPB = 256;
+
+// =========================================================================================
+// upfirdn2d  (reference: modelling/nvidia_ops.py:18-34)
+// Polyphase form: for output (oy, ox) only taps i with (oy*down + i - py1) % up == 0 touch a
+// real sample, so the tap loops start at the first such tap and step by `up`; no zero-stuffed
+// tensor is ever materialised.
+// =========================================================================================
+template <typename T, int V>
+__global__ void __launch_bounds__(TPB) upfirdn2d_k(const T* __restrict__ x, const float* __restrict__ taps,
+                                                   T* __restrict__ y, int H, int W, int C, int ky, int kx, int up,
+                                                   int down, int px1, int py1, int Ho, int Wo, int64_t total) {
+    const int64_t idx = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (idx >= total) return;
+    const int cv = C / V;
+    const int c = (int)(idx % cv) * V;
+    int64_t p = idx / cv;
+    const int ox = (int)(p % Wo);
+    p /= Wo;
+    const int oy = (int)(p % Ho);
+    const int64_t n = p / Ho;
+
+    const int by = oy * down - py1;
+    const int bx = ox * down - px1;
+    int i0 = (-by) % up;
+    if (i0 < 0) i0 += up;
+    int j0 = (-bx) % up;
+    if (j0 < 0) j0 += up;
+
+    float acc[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) acc[e] = 0.f;
+
+    for (int i = i0; i < ky; i += up) {
+        const int iy = (by + i) / up;  // exact: by + i is a multiple of up
+        if (iy < 0 || iy >= H) continue;
+        for (int j = j0; j < kx; j += up) {
+            const int ix = (bx + j) / up;
+            if (ix < 0 || ix >= W) continue;
+            const float t = taps[i * kx + j];
+            float v[V];
+            load_f<T, V>(x + ((n * H + iy) * W + ix) * C + c, v);
+#pragma unroll
+            for (int e = 0; e < V; ++e) acc[e] = fmaf(t, v[e], acc[e]);
+        }
+    }
+    store_f<T, V>(y + idx * V, acc);
+}
+
+template <typename T>
+static int upfirdn2d_launch(const void* x, const float* taps, void* y, int N, int H, int W, int C, int ky, int kx,
+                            int up, int down, int px1, int py1, int Ho, int Wo, hipStream_t st) {
+    constexpr int VV = VecOf<T>::V;
+    const bool vec = (C % VV) == 0;
+    const int64_t total = (int64_t)N * Ho * Wo * (vec ? C / VV : C);
+    if (total == 0) return GAN_OK;
+    const int64_t blocks = ceil_div64(total, TPB);
+    GAN_CHECK_ARG(blocks < (1LL << 31), "upfirdn2d: tensor too large");
+    if (vec)
+        hipLaunchKernelGGL((upfirdn2d_k<T, VV>), dim3((unsigned)blocks), dim3(TPB), 0, st, (const T*)x, taps, (T*)y, H,
+                           W, C, ky, kx, up, down, px1, py1, Ho, Wo, total);
+    else
+        hipLaunchKernelGGL((upfirdn2d_k<T, 1>), dim3((unsigned)blocks), dim3(TPB), 0, st, (const T*)x, taps, (T*)y, H,
+                           W, C, ky, kx, up, down, px1, py1, Ho, Wo, total);
+    GAN_CHECK_LAUNCH("upfirdn2d");
+    return GAN_OK;
+}
+
+extern "C" int gan_upfirdn2d(const void* x, const float* taps, void* y, int N, int H, int W, int C, int ky, int kx,
+                             int up, int down, int px1, int py1, int Ho, int Wo, int dtype, gan_stream_t stream) {
+    GAN_CHECK_ARG(N >= 0 && H > 0 && W > 0 && C > 0 && Ho >= 0 && Wo >= 0, "upfirdn2d: bad shape");
+    if (N == 0 || Ho == 0 || Wo == 0) return GAN_OK;  // empty batch: nothing to launch, pointers may be null
+    GAN_CHECK_ARG(x && taps && y, "upfirdn2d: null pointer");
+    GAN_CHECK_ARG(ky >= 1 && kx >= 1 && ky <= 64 && kx <= 64, "upfirdn2d: bad FIR size %dx%d", ky, kx);
+    GAN_CHECK_ARG(up >= 1 && down >= 1, "upfirdn2d: up/down must be >= 1");
+    GAN_CHECK_ARG(dtype == GAN_F32 || dtype == GAN_BF16, "upfirdn2d: bad dtype %d", dtype);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == GAN_F32) return upfirdn2d_launch<float>(x, taps, y, N, H, W, C, ky, kx, up, down, px1, py1, Ho, Wo, st);
+    return upfirdn2d_launch<bf16>(x, taps, y, N, H, W, C, ky, kx, up, down, px1, py1, Ho, Wo, st);
+}
+
+// =========================================================================================
+// fused affine + noise + residual + leaky-ReLU forward
+// =========================================================================================
+template <typename T, int V>
+__global__ void __launch_bounds__(TPB) affine_act_fwd_k(const T* __restrict__ x, const float* __restrict__ a,
+                                                        int64_t a_sn, const float* __restrict__ b,
+                                                        const T* __restrict__ noise, const float* __restrict__ ns,
+                                                        const T* __restrict__ r, T* __restrict__ y, int64_t HW, int C,
+                                                        int64_t total, float slope) {
+    const int64_t idx = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (idx >= total) return;
+    const int cv = C / V;
+    const int c = (int)(idx % cv) * V;
+    const int64_t pix = idx / cv;
+    float v[V];
+    load_f<T, V>(x + idx * V, v);
+    if (a) {
+        const int64_t n = pix / HW;
+#pragma unroll
+        for (int e = 0; e < V; ++e) v[e] *= a[n * a_sn + c + e];
+    }
+    if (b) {
+#pragma unroll
+        for (int e = 0; e < V; ++e) v[e] += b[c + e];
+    }
+    if (noise) {
+        const float nz = (float)noise[pix];
+#pragma unroll
+        for (int e = 0; e < V; ++e) v[e] = fmaf(nz, ns[c + e], v[e]);
+    }
+    if (r) {
+        float rv[V];
+        load_f<T, V>(r + idx * V, rv);
+#pragma unroll
+        for (int e = 0; e < V; ++e) v[e] += rv[e];
+    }
+#pragma unroll
+    for (int e = 0; e < V; ++e) v[e] = lrelu_f(v[e], slope);
+    store_f<T, V>(y + idx * V, v);
+}
+
+template <typename T>
+static int affine_act_fwd_launch(const void* x, const float* a, int64_t a_sn, const float* b, const void* noise,
+                                 const float* ns, const void* r, void* y, int N, int64_t HW, int C, float slope,
+                                 hipStream_t st) {
+    constexpr int VV = VecOf<T>::V;
+    const bool vec = (C % VV) == 0;
+    const int64_t total = (int64_t)N * HW * (vec ? C / VV : C);
+    if (total == 0) return GAN_OK;
+    const int64_t blocks = ceil_div64(total, TPB);
+    GAN_CHECK_ARG(blocks < (1LL << 31), "affine_act_fwd: tensor too large");
+    if (vec)
+        hipLaunchKernelGGL((affine_act_fwd_k<T, VV>), dim3((unsigned)blocks), dim3(TPB), 0, st, (const T*)x, a, a_sn, b,
+                           (const T*)noise, ns, (const T*)r, (T*)y, HW, C, total, slope);
+    else
+        hipLaunchKernelGGL((affine_act_fwd_k<T, 1>), dim3((unsigned)blocks), dim3(TPB), 0, st, (const T*)x, a, a_sn, b,
+                           (const T*)noise, ns, (const T*)r, (T*)y, HW, C, total, slope);
+    GAN_CHECK_LAUNCH("affine_act_fwd");
+    return GAN_OK;
+}
+
+extern "C" int gan_affine_act_fwd(const void* x, const float* a, int64_t a_stride_n, const float* b, const void* noise,
+                                  const float* ns, const void* r, void* y, int N, int64_t HW, int C, float slope,
+                                  int dtype, gan_stream_t stream) {
+    GAN_CHECK_ARG(N >= 0 && HW >= 0 && C > 0, "affine_act_fwd: bad shape");
+    if (N == 0 || HW == 0) return GAN_OK;
+    GAN_CHECK_ARG(x && y, "affine_act_fwd: null pointer");
+    GAN_CHECK_ARG((noise == nullptr) == (ns == nullptr), "affine_act_fwd: noise and noise scale go together");
+    GAN_CHECK_ARG(a_stride_n == 0 || a_stride_n == C, "affine_act_fwd: a_stride_n must be 0 or C");
+    GAN_CHECK_ARG(dtype == GAN_F32 || dtype == GAN_BF16, "affine_act_fwd: bad dtype %d", dtype);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == GAN_F32) return affine_act_fwd_launch<float>(x, a, a_stride_n, b, noise, ns, r, y, N, HW, C, slope, st);
+    return affine_act_fwd_launch<bf16>(x, a, a_stride_n, b, noise, ns, r, y, N, HW, C, slope, st);
+}
+
+// =========================================================================================
+// out = g * m(ymask) * a      (backward / double-backward building block)
+// =========================================================================================
+template <typename T, int V>
+__global__ void __launch_bounds__(TPB) mask_scale_k(const T* __restrict__ g, const T* __restrict__ ymask,
+                                                    const float* __restrict__ a, int64_t a_sn, T* __restrict__ out,
+                                                    int64_t HW, int C, int64_t total, float slope) {
+    const int64_t idx = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (idx >= total) return;
+    const int cv = C / V;
+    const int c = (int)(idx % cv) * V;
+    float v[V];
+    load_f<T, V>(g + idx * V, v);
+    if (ymask) {
+        float m[V];
+        load_f<T, V>(ymask + idx * V, m);
+#pragma unroll
+        for (int e = 0; e < V; ++e) v[e] *= lrelu_mask(m[e], slope);
+    }
+    if (a) {
+        const int64_t n = (idx / cv) / HW;
+#pragma unroll
+        for (int e = 0; e < V; ++e) v[e] *= a[n * a_sn + c + e];
+    }
+    store_f<T, V>(out + idx * V, v);
+}
+
+template <typename T>
+static int mask_scale_launch(const void* g, const void* ymask, const float* a, int64_t a_sn, void* out, int N,
+                             int64_t HW, int C, float slope, hipStream_t st) {
+    constexpr int VV = VecOf<T>::V;
+    const bool vec = (C % VV) == 0;
+    const int64_t total = (int64_t)N * HW * (vec ? C / VV : C);
+    if (total == 0) return GAN_OK;
+    const int64_t blocks = ceil_div64(total, TPB);
+    GAN_CHECK_ARG(blocks < (1LL << 31), "mask_scale: tensor too large");
+    if (vec)
+        hipLaunchKernelGGL((mask_scale_k<T, VV>), dim3((unsigned)blocks), dim3(TPB), 0, st, (const T*)g,
+                           (const T*)ymask, a, a_sn, (T*)out, HW, C, total, slope);
+    else
+        hipLaunchKernelGGL((mask_scale_k<T, 1>), dim3((unsigned)blocks), dim3(TPB), 0, st, (const T*)g, (const T*)ymask,
+                           a, a_sn, (T*)out, HW, C, total, slope);
+    GAN_CHECK_LAUNCH("mask_scale");
+    return GAN_OK;
+}
+
+extern "C" int gan_mask_scale(const void* g, const void* ymask, const float* a, int64_t a_stride_n, void* out, int N,
+                              int64_t HW, int C, float slope, int dtype, gan_stream_t stream) {
+    GAN_CHECK_ARG(N >= 0 && HW >= 0 && C > 0, "mask_scale: bad shape");
+    if (N == 0 || HW == 0) return GAN_OK;
+    GAN_CHECK_ARG(g && out, "mask_scale: null pointer");
+    GAN_CHECK_ARG(a_stride_n == 0 || a_stride_n == C, "mask_scale: a_stride_n must be 0 or C");
+    GAN_CHECK_ARG(dtype == GAN_F32 || dtype == GAN_BF16, "mask_scale: bad dtype %d", dtype);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == GAN_F32) return mask_scale_launch<float>(g, ymask, a, a_stride_n, out, N, HW, C, slope, st);
+    return mask_scale_launch<bf16>(g, ymask, a, a_stride_n, out, N, HW, C, slope, st);
+}
+
+// =========================================================================================
+// channel reductions:  out[n*out_sn + c] += sum_hw A * m(ymask) * Bterm
+// Block = [R rows][CVT channel vectors]; each thread walks rows r, r+R, ...; partial sums are
+// folded across the lanes of a wave that hold the same channel vector with __shfl_xor (when
+// CVT is a power of two below 64), then across waves through LDS, then one fp32 atomic per
+// channel per block.
+// =========================================================================================
+template <typename T, int V>
+__global__ void __launch_bounds__(TPB) chan_dot_k(const T* __restrict__ A, const T* __restrict__ B, int b_mode,
+                                                  const T* __restrict__ ymask, float slope, float* __restrict__ out,
+                                                  int64_t out_sn, int64_t HW, int C, int CVT, int R,
+                                                  int64_t rows_per_block) {
+    __shared__ float red[TPB * V];
+    const int tid = threadIdx.x;
+    const int tv = tid % CVT;
+    const int tr = tid / CVT;
+    const int64_t n = blockIdx.y;
+    const int cv = C / V;
+    const int vec = blockIdx.z * CVT + tv;  // channel vector index
+    const bool active = (tr < R) && (vec < cv);
+    const int c = vec * V;
+
+    float acc[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) acc[e] = 0.f;
+
+    if (active) {
+        const int64_t row0 = (int64_t)blockIdx.x * rows_per_block;
+        int64_t row1 = row0 + rows_per_block;
+        if (row1 > HW) row1 = HW;
+        for (int64_t row = row0 + tr; row < row1; row += R) {
+            const int64_t pix = n * HW + row;
+            const int64_t off = pix * C + c;
+            float v[V];
+            load_f<T, V>(A + off, v);
+            if (ymask) {
+                float m[V];
+                load_f<T, V>(ymask + off, m);
+#pragma unroll
+                for (int e = 0; e < V; ++e) v[e] *= lrelu_mask(m[e], slope);
+            }
+            if (b_mode == 1) {
+                float w[V];
+                load_f<T, V>(B + off, w);
+#pragma unroll
+                for (int e = 0; e < V; ++e) acc[e] = fmaf(v[e], w[e], acc[e]);
+            } else if (b_mode == 2) {
+                const float w = (float)B[pix];
+#pragma unroll
+                for (int e = 0; e < V; ++e) acc[e] = fmaf(v[e], w, acc[e]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < V; ++e) acc[e] += v[e];
+            }
+        }
+    }
+
+    const bool pow2 = (CVT & (CVT - 1)) == 0 && CVT < 64;
+    if (pow2) {
+        // lanes l, l+CVT, l+2CVT, ... of a wave hold the same channel vector (TPB % CVT == 0,
+        // so idle threads do not exist and every lane carries a valid partial or zeros).
+        for (int off = CVT; off < 64; off <<= 1) {
+#pragma unroll
+            for (int e = 0; e < V; ++e) acc[e] += __shfl_xor(acc[e], off);
+        }
+        const int lane = tid & 63;
+        const int wave = tid >> 6;
+        if (lane < CVT) {
+#pragma unroll
+            for (int e = 0; e < V; ++e) red[(wave * CVT + lane) * V + e] = acc[e];
+        }
+        __syncthreads();
+        if (tid < CVT && (blockIdx.z * CVT + tid) < cv) {
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                float s = 0.f;
+                for (int w = 0; w < TPB / 64; ++w) s += red[(w * CVT + tid) * V + e];
+                atomicAdd(out + n * out_sn + (int64_t)(blockIdx.z * CVT + tid) * V + e, s);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < V; ++e) red[tid * V + e] = acc[e];
+        __syncthreads();
+        if (tr == 0 && vec < cv) {
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                float s = 0.f;
+                for (int r = 0; r < R; ++r) s += red[(r * CVT + tv) * V + e];
+                atomicAdd(out + n * out_sn + c + e, s);
+            }
+        }
+    }
+}
+
+template <typename T>
+static int chan_dot_launch(const void* A, const void* B, int b_mode, const void* ymask, float slope, float* out,
+                           int64_t out_sn, int N, int64_t HW, int C, hipStream_t st) {
+    constexpr int VV = VecOf<T>::V;
+    const bool vec = (C % VV) == 0;
+    const int V = vec ? VV : 1;
+    const int cv = C / V;
+    const int CVT = cv < TPB ? cv : TPB;
+    const int R = TPB / CVT;
+    const int zchunks = (cv + CVT - 1) / CVT;
+    int64_t bps = ceil_div64(HW, (int64_t)R * 4);  // >= 4 rows per thread when possible
+    const int64_t cap = 4096 / ((int64_t)N * zchunks) > 0 ? 4096 / ((int64_t)N * zchunks) : 1;
+    if (bps > cap) bps = cap;
+    if (bps < 1) bps = 1;
+    int64_t rpb = ceil_div64(HW, bps);
+    rpb = ceil_div64(rpb, R) * R;
+    bps = ceil_div64(HW, rpb);
+    GAN_CHECK_ARG(N <= 65535 && zchunks <= 65535, "chan_dot: N or C too large for the grid");
+    dim3 grid((unsigned)bps, (unsigned)N, (unsigned)zchunks);
+    if (vec)
+        hipLaunchKernelGGL((chan_dot_k<T, VV>), grid, dim3(TPB), 0, st, (const T*)A, (const T*)B, b_mode,
+                           (const T*)ymask, slope, out, out_sn, HW, C, CVT, R, rpb);
+    else
+        hipLaunchKernelGGL((chan_dot_k<T, 1>), grid, dim3(TPB), 0, st, (const T*)A, (const T*)B, b_mode,
+                           (const T*)ymask, slope, out, out_sn, HW, C, CVT, R, rpb);
+    GAN_CHECK_LAUNCH("chan_dot");
+    return GAN_OK;
+}
+
+extern "C" int gan_chan_dot(const void* A, const void* B, int b_mode, const void* ymask, float slope, float* out,
+                            int64_t out_stride_n, int N, int64_t HW, int C, int dtype, gan_stream_t stream) {
+    GAN_CHECK_ARG(N >= 0 && HW >= 0 && C > 0, "chan_dot: bad shape");
+    GAN_CHECK_ARG((A || N == 0 || HW == 0) && (out || (out_stride_n && N == 0)), "chan_dot: null pointer");
+    GAN_CHECK_ARG(b_mode >= 0 && b_mode <= 2 && ((b_mode == 0) == (B == nullptr)), "chan_dot: b_mode %d vs B", b_mode);
+    GAN_CHECK_ARG(out_stride_n == 0 || out_stride_n == C, "chan_dot: out_stride_n must be 0 or C");
+    GAN_CHECK_ARG(dtype == GAN_F32 || dtype == GAN_BF16, "chan_dot: bad dtype %d", dtype);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t bytes = sizeof(float) * (size_t)(out_stride_n ? (int64_t)N * C : C);
+    if (bytes == 0) return GAN_OK;
+    if (hipMemsetAsync(out, 0, bytes, st) != hipSuccess) {
+        gan_set_error("chan_dot: memset failed");
+        return GAN_ERR_LAUNCH;
+    }
+    if (N == 0 || HW == 0) return GAN_OK;
+    if (dtype == GAN_F32) return chan_dot_launch<float>(A, B, b_mode, ymask, slope, out, out_stride_n, N, HW, C, st);
+    return chan_dot_launch<bf16>(A, B, b_mode, ymask, slope, out, out_stride_n, N, HW, C, st);
+}
+
+// =========================================================================================
+// MinibatchStdDev statistic (reference: modelling/progressive_gan.py:25-36)
+// one workgroup per group column j; two-pass variance over the G members in registers.
+// =========================================================================================
+template <typename T>
+__global__ void __launch_bounds__(TPB) mbstd_fwd_k(const T* __restrict__ x, float* __restrict__ stat, int M, int G,
+                                                   int64_t E /* HW*C */) {
+    __shared__ float red[TPB / 64];
+    const int j = blockIdx.x;
+    float acc = 0.f;
+    for (int64_t e = threadIdx.x; e < E; e += TPB) {
+        float mean = 0.f;
+        for (int k = 0; k < G; ++k) mean += (float)x[((int64_t)(j + k * M)) * E + e];
+        mean /= (float)G;
+        float var = 0.f;
+        for (int k = 0; k < G; ++k) {
+            const float d = (float)x[((int64_t)(j + k * M)) * E + e] - mean;
+            var = fmaf(d, d, var);
+        }
+        acc += sqrtf(var / (float)G + 1e-6f);
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+        for (int w = 0; w < TPB / 64; ++w) s += red[w];
+        stat[j] = s / (float)E;
+    }
+}
+
+extern "C" int gan_mbstd_fwd(const void* x, float* stat, int N, int G, int64_t HW, int C, int dtype,
+                             gan_stream_t stream) {
+    GAN_CHECK_ARG(x && stat, "mbstd_fwd: null pointer");
+    GAN_CHECK_ARG(G >= 1 && N > 0 && N % G == 0, "mbstd_fwd: batch %d is not a multiple of group size %d", N, G);
+    GAN_CHECK_ARG(HW > 0 && C > 0, "mbstd_fwd: bad shape");
+    GAN_CHECK_ARG(dtype == GAN_F32 || dtype == GAN_BF16, "mbstd_fwd: bad dtype %d", dtype);
+    hipStream_t st = (hipStream_t)stream;
+    const int M = N / G;
+    if (dtype == GAN_F32)
+        hipLaunchKernelGGL((mbstd_fwd_k<float>), dim3(M), dim3(TPB), 0, st, (const float*)x, stat, M, G, HW * C);
+    else
+        hipLaunchKernelGGL((mbstd_fwd_k<bf16>), dim3(M), dim3(TPB), 0, st, (const bf16*)x, stat, M, G, HW * C);
+    GAN_CHECK_LAUNCH("mbstd_fwd");
+    return GAN_OK;
+}
+
+// =========================================================================================
+// EMA lerp over one flat fp32 arena (reference: utils.py:95-96)
+// =========================================================================================
+__global__ void __launch_bounds__(TPB) ema_lerp_k(float* __restrict__ ema, const float* __restrict__ p, int64_t n4,
+                                                  int64_t n, float w) {
+    const int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (i < n4) {
+        float4 e = reinterpret_cast<float4*>(ema)[i];
+        const float4 q = reinterpret_cast<const float4*>(p)[i];
+        e.x = fmaf(q.x - e.x, w, e.x);
+        e.y = fmaf(q.y - e.y, w, e.y);
+        e.z = fmaf(q.z - e.z, w, e.z);
+        e.w = fmaf(q.w - e.w, w, e.w);
+        reinterpret_cast<float4*>(ema)[i] = e;
+    } else {
+        const int64_t t = n4 * 4 + (i - n4);
+        if (t < n) ema[t] = fmaf(p[t] - ema[t], w, ema[t]);
+    }
+}
+
+extern "C" int gan_ema_lerp(float* ema, const float* p, int64_t n, float weight, gan_stream_t stream) {
+    GAN_CHECK_ARG(ema && p, "ema_lerp: null pointer");
+    GAN_CHECK_ARG(n >= 0, "ema_lerp: negative size");
+    GAN_CHECK_ARG(((uintptr_t)ema % 16) == 0 && ((uintptr_t)p % 16) == 0, "ema_lerp: arenas must be 16-byte aligned");
+    if (n == 0) return GAN_OK;
+    const int64_t n4 = n / 4;
+    const int64_t threads = n4 + (n - n4 * 4);
+    const int64_t blocks = ceil_div64(threads, TPB);
+    GAN_CHECK_ARG(blocks < (1LL << 31), "ema_lerp: arena too large");
+    hipLaunchKernelGGL(ema_lerp_k, dim3((unsigned)blocks), dim3(TPB), 0, (hipStream_t)stream, ema, p, n4, n, weight);
+    GAN_CHECK_LAUNCH("ema_lerp");
+    return GAN_OK;
+}

@@ -1,0 +1,593 @@
+"""Differentiable ops over the HIP kernels of libgan_amd.so.
+
+Layout: every activation is a 4-D tensor of logical shape (N, C, H, W) -- the shape the
+reference's modules see -- stored channels-last (C fastest), fp32 or bf16.
+
+Differentiation: each `torch.autograd.Function` below expresses its backward through other
+Functions of this file (the pattern of the reference's UpFIRDn2d, modelling/nvidia_ops.py:40-54),
+so gradients of any order -- R1 and WGAN-GP need second order through the discriminator
+(losses.py:89-103) -- run on the same HIP kernels and never fall back to autograd-of-autograd over
+PyTorch ops.  The primitive set is closed under differentiation:
+
+    conv2d  <-> conv2d_dgrad <-> conv2d_wgrad          (a convolution is bilinear in x and W)
+    upfirdn2d <-> upfirdn2d (flipped taps, up/down swapped)
+    chan_scale <-> chan_dot                             (x * a[n,c]  and  sum_hw A*B)
+    mask_mul(g, y) = g * lrelu'(y)                      (linear in g; d/dy = 0 almost everywhere)
+
+Fused forward kernels (affine_act, modulated conv) are Functions whose backward is composed of
+these primitives.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+from torch import Tensor
+from torch.autograd import Function
+
+from . import _lib
+from ._lib import check, dtype_code, ptr, require_gpu, stream_of
+
+CL = torch.channels_last
+
+
+# ======================================================================================
+# raw (non-differentiable) kernel launchers
+# ======================================================================================
+def as_cl(x: Tensor) -> Tensor:
+    """4-D tensor, dense, channels-last."""
+    if x.dim() != 4:
+        raise _lib.GanAmdError(f"expected a 4-D (N, C, H, W) tensor, got shape {tuple(x.shape)}")
+    return x.contiguous(memory_format=CL)
+
+
+def _empty_like_cl(x: Tensor, shape) -> Tensor:
+    return torch.empty(shape, dtype=x.dtype, device=x.device, memory_format=CL)
+
+
+def _f32(t: Optional[Tensor]) -> Optional[Tensor]:
+    if t is None:
+        return None
+    t = t.detach()
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def raw_upfirdn2d(x: Tensor, taps: Tensor, up: int, down: int, px1: int, py1: int, ho: int, wo: int) -> Tensor:
+    require_gpu(x, taps)
+    lib = _lib.load()
+    x = as_cl(x.detach())
+    taps32 = _f32(taps)
+    n, c, h, w = x.shape
+    ky, kx = taps32.shape
+    y = _empty_like_cl(x, (n, c, ho, wo))
+    check(
+        lib.gan_upfirdn2d(ptr(x), ptr(taps32), ptr(y), n, h, w, c, ky, kx, up, down, px1, py1, ho, wo, dtype_code(x), stream_of(x)),
+        "gan_upfirdn2d",
+    )
+    return y
+
+
+def _side(t: Optional[Tensor], n: int, c: int, what: str) -> Tuple[Optional[Tensor], int]:
+    """fp32 side vector: (C,) -> stride 0, (N, C) -> stride C."""
+    if t is None:
+        return None, 0
+    t = _f32(t)
+    if t.numel() == c:
+        return t.reshape(c), 0
+    if t.numel() == n * c:
+        return t.reshape(n, c), c
+    raise _lib.GanAmdError(f"{what}: expected {c} or {n}x{c} values, got shape {tuple(t.shape)}")
+
+
+def raw_affine_act(
+    x: Tensor,
+    a: Optional[Tensor] = None,
+    b: Optional[Tensor] = None,
+    noise: Optional[Tensor] = None,
+    ns: Optional[Tensor] = None,
+    r: Optional[Tensor] = None,
+    slope: float = 1.0,
+) -> Tensor:
+    require_gpu(x, a, b, noise, ns, r)
+    lib = _lib.load()
+    x = as_cl(x.detach())
+    n, c, h, w = x.shape
+    a32, a_sn = _side(a, n, c, "affine_act a")
+    b32, _ = _side(b, 1, c, "affine_act b")
+    ns32, _ = _side(ns, 1, c, "affine_act noise scale")
+    if noise is not None:
+        noise = noise.detach().to(x.dtype).reshape(n, h * w).contiguous()
+    if r is not None:
+        r = as_cl(r.detach().to(x.dtype))
+        assert r.shape == x.shape
+    y = _empty_like_cl(x, x.shape)
+    check(
+        lib.gan_affine_act_fwd(
+            ptr(x), ptr(a32), a_sn, ptr(b32), ptr(noise), ptr(ns32), ptr(r), ptr(y), n, h * w, c, float(slope), dtype_code(x), stream_of(x)
+        ),
+        "gan_affine_act_fwd",
+    )
+    return y
+
+
+def raw_mask_scale(g: Tensor, ymask: Optional[Tensor], a: Optional[Tensor], slope: float) -> Tensor:
+    require_gpu(g, ymask, a)
+    lib = _lib.load()
+    g = as_cl(g.detach())
+    n, c, h, w = g.shape
+    if ymask is not None:
+        ymask = as_cl(ymask.detach().to(g.dtype))
+        assert ymask.shape == g.shape
+    a32, a_sn = _side(a, n, c, "mask_scale a")
+    out = _empty_like_cl(g, g.shape)
+    check(
+        lib.gan_mask_scale(ptr(g), ptr(ymask), ptr(a32), a_sn, ptr(out), n, h * w, c, float(slope), dtype_code(g), stream_of(g)),
+        "gan_mask_scale",
+    )
+    return out
+
+
+def raw_chan_dot(A: Tensor, B: Optional[Tensor], b_mode: int, ymask: Optional[Tensor], slope: float, per_sample: bool) -> Tensor:
+    """fp32 (N, C) if per_sample else (C,)."""
+    require_gpu(A, B, ymask)
+    lib = _lib.load()
+    A = as_cl(A.detach())
+    n, c, h, w = A.shape
+    if b_mode == 1:
+        B = as_cl(B.detach().to(A.dtype))
+        assert B.shape == A.shape
+    elif b_mode == 2:
+        B = B.detach().to(A.dtype).reshape(n, h * w).contiguous()
+    else:
+        B = None
+    if ymask is not None:
+        ymask = as_cl(ymask.detach().to(A.dtype))
+    out = torch.empty((n, c) if per_sample else (c,), dtype=torch.float32, device=A.device)
+    check(
+        lib.gan_chan_dot(ptr(A), ptr(B), b_mode, ptr(ymask), float(slope), ptr(out), c if per_sample else 0, n, h * w, c, dtype_code(A), stream_of(A)),
+        "gan_chan_dot",
+    )
+    return out
+
+
+def _pad_channels(x: Tensor, mult: int) -> Tensor:
+    c = x.shape[1]
+    rem = (-c) % mult
+    if rem == 0:
+        return as_cl(x)
+    return as_cl(F.pad(x, (0, 0, 0, 0, 0, rem)))
+
+
+def pack_weight(weight: Tensor, dtype: torch.dtype, cin_mult: int = 8) -> Tuple[Tensor, int, int]:
+    """(Cout, Cin, kh, kw) -> GEMM-B layout [Cout][Kpad], k = tap*Cin_p + ci, zero padded; returns (wt, Cin_p, Kpad)."""
+    cout, cin, kh, kw = weight.shape
+    w = weight.detach().permute(0, 2, 3, 1)  # (Cout, kh, kw, Cin)
+    cin_p = cin + ((-cin) % cin_mult)
+    if cin_p != cin:
+        w = F.pad(w, (0, cin_p - cin))
+    k = kh * kw * cin_p
+    kpad = k + ((-k) % 32)
+    w = w.reshape(cout, k)
+    if kpad != k:
+        w = F.pad(w, (0, kpad - k))
+    return w.to(dtype).contiguous(), cin_p, kpad
+
+
+def raw_conv2d(
+    x: Tensor,
+    weight: Tensor,
+    py: int,
+    px: int,
+    *,
+    up2: bool = False,
+    in_scale: Optional[Tensor] = None,
+    out_scale: Optional[Tensor] = None,
+    bias: Optional[Tensor] = None,
+    noise: Optional[Tensor] = None,
+    noise_scale: Optional[Tensor] = None,
+    slope: float = 1.0,
+) -> Tensor:
+    """Stride-1 correlation of channels-last x with weight (Cout, Cin, kh, kw) + fused prologue/epilogue."""
+    require_gpu(x, weight, in_scale, out_scale, bias, noise, noise_scale)
+    lib = _lib.load()
+    x = _pad_channels(x.detach(), 8)
+    n, cin_p, h, w = x.shape
+    cout, cin, kh, kw = weight.shape
+    wt, cin_p2, kpad = pack_weight(weight, x.dtype)
+    if cin_p2 != cin_p:
+        raise _lib.GanAmdError(f"conv2d: input has {x.shape[1]} (padded) channels, weight expects {cin}")
+    hl, wl = (2 * h, 2 * w) if up2 else (h, w)
+    ho, wo = hl + 2 * py - kh + 1, wl + 2 * px - kw + 1
+    if ho <= 0 or wo <= 0:
+        raise _lib.GanAmdError("conv2d: empty output")
+    if in_scale is not None:
+        in_scale = _f32(in_scale).reshape(n, cin)
+        if cin_p != cin:
+            in_scale = F.pad(in_scale, (0, cin_p - cin)).contiguous()
+    out_scale32, _ = _side(out_scale, n, cout, "conv2d out_scale")
+    if out_scale32 is not None and out_scale32.numel() != n * cout:
+        out_scale32 = out_scale32.reshape(1, cout).expand(n, cout).contiguous()
+    bias32, _ = _side(bias, 1, cout, "conv2d bias")
+    ns32, _ = _side(noise_scale, 1, cout, "conv2d noise scale")
+    if noise is not None:
+        noise = noise.detach().to(x.dtype).reshape(n, ho * wo).contiguous()
+    y = _empty_like_cl(x, (n, cout, ho, wo))
+    check(
+        lib.gan_conv2d_fwd(
+            ptr(x), ptr(wt), ptr(y), ptr(in_scale), ptr(out_scale32), ptr(bias32), ptr(noise), ptr(ns32), float(slope),
+            n, h, w, cin_p, int(up2), ho, wo, cout, kh, kw, py, px, kpad, dtype_code(x), stream_of(x),
+        ),
+        "gan_conv2d_fwd",
+    )
+    return y
+
+
+def raw_conv2d_dgrad(gy: Tensor, weight: Tensor, py: int, px: int, *, out_scale: Optional[Tensor] = None) -> Tensor:
+    """Input gradient of a stride-1 correlation = correlation of gy with the transposed, flipped
+    weights and padding k-1-p.  Output spatial size is the forward input size."""
+    cout, cin, kh, kw = weight.shape
+    wt = weight.detach().flip(2, 3).transpose(0, 1)  # (Cin, Cout, kh, kw)
+    return raw_conv2d(gy, wt, kh - 1 - py, kw - 1 - px, out_scale=out_scale)
+
+
+def raw_conv2d_wgrad(
+    x: Tensor, gy: Tensor, kh: int, kw: int, py: int, px: int, *, up2: bool = False, in_scale: Optional[Tensor] = None
+) -> Tensor:
+    """fp32 (Cout, Cin, kh, kw)."""
+    require_gpu(x, gy, in_scale)
+    lib = _lib.load()
+    cin, cout = x.shape[1], gy.shape[1]
+    gy = gy.detach().to(x.dtype)
+    x = _pad_channels(x.detach(), 16)
+    gy = _pad_channels(gy, 16)
+    n, cin_p, h, w = x.shape
+    cout_p, ho, wo = gy.shape[1], gy.shape[2], gy.shape[3]
+    if in_scale is not None:
+        in_scale = _f32(in_scale).reshape(n, cin)
+        if cin_p != cin:
+            in_scale = F.pad(in_scale, (0, cin_p - cin)).contiguous()
+    dw = torch.empty((kh * kw, cout_p, cin_p), dtype=torch.float32, device=x.device)
+    check(
+        lib.gan_conv2d_wgrad(
+            ptr(x), ptr(gy), ptr(dw), ptr(in_scale), n, h, w, cin_p, int(up2), ho, wo, cout_p, kh, kw, py, px, dtype_code(x), stream_of(x)
+        ),
+        "gan_conv2d_wgrad",
+    )
+    return dw[:, :cout, :cin].reshape(kh, kw, cout, cin).permute(2, 3, 0, 1).contiguous()
+
+
+def raw_mbstd_stat(x: Tensor, group: int) -> Tensor:
+    require_gpu(x)
+    lib = _lib.load()
+    x = as_cl(x.detach())
+    n, c, h, w = x.shape
+    stat = torch.empty((n // group,), dtype=torch.float32, device=x.device)
+    check(lib.gan_mbstd_fwd(ptr(x), ptr(stat), n, group, h * w, c, dtype_code(x), stream_of(x)), "gan_mbstd_fwd")
+    return stat
+
+
+def raw_ema_lerp(ema_flat: Tensor, p_flat: Tensor, weight: float) -> None:
+    require_gpu(ema_flat, p_flat)
+    lib = _lib.load()
+    assert ema_flat.dtype == torch.float32 and p_flat.dtype == torch.float32
+    assert ema_flat.is_contiguous() and p_flat.is_contiguous() and ema_flat.numel() == p_flat.numel()
+    check(lib.gan_ema_lerp(ptr(ema_flat), ptr(p_flat), ema_flat.numel(), float(weight), stream_of(ema_flat)), "gan_ema_lerp")
+
+
+# ======================================================================================
+# differentiable primitives
+# ======================================================================================
+def _need(ctx, i: int) -> bool:
+    return ctx.needs_input_grad[i]
+
+
+class UpFirDnFn(Function):
+    """upfirdn2d with a general, shape-exact adjoint.  The reference's UpFIRDn2d.backward
+    (nvidia_ops.py:50-54) calls itself with the flipped kernel, up<->down and swapped pads, which is
+    the true adjoint only when p1 + p2 == k - 1; here the backward pads are derived from the shapes
+    (begin pad k-1-p1, output size = forward input size), which equals the reference wherever the
+    reference's backward runs and is also right elsewhere.  No gradient for the FIR taps
+    (nvidia_ops.py:54)."""
+
+    @staticmethod
+    def forward(ctx, x, taps, up, down, px1, px2, py1, py2, ho=None, wo=None):
+        n, c, h, w = x.shape
+        ky, kx = taps.shape
+        if ho is None:
+            ho = (h * up + py1 + py2 - ky) // down + 1
+            wo = (w * up + px1 + px2 - kx) // down + 1
+        if ho <= 0 or wo <= 0:
+            raise _lib.GanAmdError(f"upfirdn2d: empty output for input {h}x{w}")
+        ctx.save_for_backward(taps)
+        ctx.cfg = (up, down, px1, py1, h, w, ho, wo, ky, kx)
+        return raw_upfirdn2d(x, taps, up, down, px1, py1, ho, wo)
+
+    @staticmethod
+    def backward(ctx, gy):
+        (taps,) = ctx.saved_tensors
+        up, down, px1, py1, h, w, ho, wo, ky, kx = ctx.cfg
+        gx = None
+        if _need(ctx, 0):
+            a1x, a1y = kx - 1 - px1, ky - 1 - py1
+            a2x = (w - 1) * up + kx - wo * down - a1x
+            a2y = (h - 1) * up + ky - ho * down - a1y
+            gx = UpFirDnFn.apply(gy, taps.flip(0, 1), down, up, a1x, a2x, a1y, a2y, h, w)
+        return (gx,) + (None,) * 9
+
+
+class MaskMulFn(Function):
+    """g * m(y), m(y) = 1 where y > 0 else slope: the leaky-ReLU backward as a function of the
+    activation OUTPUT.  Linear in g; the mask has zero derivative almost everywhere."""
+
+    @staticmethod
+    def forward(ctx, g, y, slope):
+        ctx.save_for_backward(y)
+        ctx.slope = slope
+        return raw_mask_scale(g, y, None, slope)
+
+    @staticmethod
+    def backward(ctx, gg):
+        (y,) = ctx.saved_tensors
+        return (MaskMulFn.apply(gg, y, ctx.slope) if _need(ctx, 0) else None), None, None
+
+
+class LreluFn(Function):
+    """nn.LeakyReLU(slope), out of place (stylegan2.py:49,56; progressive_gan.py:44,46,73)."""
+
+    @staticmethod
+    def forward(ctx, x, slope):
+        y = raw_affine_act(x, slope=slope)
+        ctx.save_for_backward(y)
+        ctx.slope = slope
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (y,) = ctx.saved_tensors
+        return MaskMulFn.apply(gy, y, ctx.slope), None
+
+
+class ChanScaleFn(Function):
+    """x * a, a of shape (C,) or (N, C) broadcast over pixels.  Bilinear."""
+
+    @staticmethod
+    def forward(ctx, x, a):
+        ctx.save_for_backward(x, a)
+        return raw_mask_scale(x, None, a, 1.0)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, a = ctx.saved_tensors
+        gx = ChanScaleFn.apply(gy, a) if _need(ctx, 0) else None
+        ga = None
+        if _need(ctx, 1):
+            ga = ChanDotFn.apply(gy, x, a.numel() != x.shape[1]).reshape(a.shape).to(a.dtype)
+        return gx, ga
+
+
+class ChanDotFn(Function):
+    """sum over pixels (and over the batch unless per_sample) of A*B -> fp32 (N, C) or (C,).  Bilinear."""
+
+    @staticmethod
+    def forward(ctx, A, B, per_sample):
+        ctx.save_for_backward(A, B)
+        ctx.per_sample = per_sample
+        return raw_chan_dot(A, B, 1, None, 1.0, per_sample)
+
+    @staticmethod
+    def backward(ctx, g):
+        A, B = ctx.saved_tensors
+        gA = ChanScaleFn.apply(B, g).to(A.dtype) if _need(ctx, 0) else None
+        gB = ChanScaleFn.apply(A, g).to(B.dtype) if _need(ctx, 1) else None
+        return gA, gB, None
+
+
+class ChanSumFn(Function):
+    """sum over pixels (and batch unless per_sample) -> fp32 (N, C) or (C,): bias / per-channel gradients."""
+
+    @staticmethod
+    def forward(ctx, A, per_sample):
+        ctx.shape = A.shape
+        ctx.dtype = A.dtype
+        ctx.per_sample = per_sample
+        return raw_chan_dot(A, None, 0, None, 1.0, per_sample)
+
+    @staticmethod
+    def backward(ctx, g):
+        n, c, h, w = ctx.shape
+        g = g.reshape(n if ctx.per_sample else 1, c, 1, 1).to(ctx.dtype)
+        return g.expand(n, c, h, w).contiguous(memory_format=CL), None
+
+
+class PixelDotFn(Function):
+    """sum_{n,hw} A[n,c,hw] * noise[n,hw] -> fp32 (C,): gradient of Noise.scale (stylegan.py:22,27).
+    The noise draw is a constant."""
+
+    @staticmethod
+    def forward(ctx, A, noise):
+        ctx.save_for_backward(noise)
+        return raw_chan_dot(A, noise, 2, None, 1.0, False)
+
+    @staticmethod
+    def backward(ctx, g):
+        (noise,) = ctx.saved_tensors
+        # d/dA = noise[n,hw] * g[c]
+        n, _, h, w = noise.shape
+        gA = noise.to(torch.float32) * g.reshape(1, -1, 1, 1)
+        return gA.to(noise.dtype).contiguous(memory_format=CL), None
+
+
+class Conv2dFn(Function):
+    """Stride-1 correlation y = conv(x, W) with zero padding (py, px); no bias (biases ride in the
+    fused epilogues).  Reference arithmetic: F.conv2d as used by nn.Conv2d (progressive_gan.py:45-50)
+    and by batched_conv2d (stylegan2.py:18,36)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, py, px):
+        ctx.save_for_backward(x, weight)
+        ctx.pad = (py, px)
+        return raw_conv2d(x, weight, py, px)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        py, px = ctx.pad
+        gx = Conv2dDgradFn.apply(gy, weight, py, px) if _need(ctx, 0) else None
+        gw = Conv2dWgradFn.apply(x, gy, weight.shape[2], weight.shape[3], py, px).to(weight.dtype) if _need(ctx, 1) else None
+        return gx, gw, None, None
+
+
+class Conv2dDgradFn(Function):
+    """gx = dgrad(gy, W): bilinear in (gy, W)."""
+
+    @staticmethod
+    def forward(ctx, gy, weight, py, px):
+        ctx.save_for_backward(gy, weight)
+        ctx.pad = (py, px)
+        return raw_conv2d_dgrad(gy, weight, py, px)
+
+    @staticmethod
+    def backward(ctx, ggx):
+        gy, weight = ctx.saved_tensors
+        py, px = ctx.pad
+        g_gy = Conv2dFn.apply(ggx, weight, py, px).to(gy.dtype) if _need(ctx, 0) else None
+        g_w = Conv2dWgradFn.apply(ggx, gy, weight.shape[2], weight.shape[3], py, px).to(weight.dtype) if _need(ctx, 1) else None
+        return g_gy, g_w, None, None
+
+
+class Conv2dWgradFn(Function):
+    """gW = wgrad(x, gy) in fp32: bilinear in (x, gy)."""
+
+    @staticmethod
+    def forward(ctx, x, gy, kh, kw, py, px):
+        ctx.save_for_backward(x, gy)
+        ctx.cfg = (kh, kw, py, px)
+        return raw_conv2d_wgrad(x, gy, kh, kw, py, px)
+
+    @staticmethod
+    def backward(ctx, ggw):
+        x, gy = ctx.saved_tensors
+        kh, kw, py, px = ctx.cfg
+        g_x = Conv2dDgradFn.apply(gy, ggw, py, px).to(x.dtype) if _need(ctx, 0) else None
+        g_gy = Conv2dFn.apply(x, ggw, py, px).to(gy.dtype) if _need(ctx, 1) else None
+        return g_x, g_gy, None, None, None, None
+
+
+class AffineActFn(Function):
+    """Fused y = lrelu_slope(x*a + b + noise*ns + r) in one HBM pass (kernel gan_affine_act_fwd).
+    a: (C,) or (N, C); b, ns: (C,); noise: (N, 1, H, W) constant; r: residual like x.
+    Backward is composed of the primitives above, so it can be differentiated again."""
+
+    @staticmethod
+    def forward(ctx, x, a, b, noise, ns, r, slope):
+        y = raw_affine_act(x, a, b, noise, ns, r, slope)
+        ctx.save_for_backward(x, a, b, noise, ns, r, y)
+        ctx.slope = slope
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, a, b, noise, ns, r, y = ctx.saved_tensors
+        gz = MaskMulFn.apply(gy, y, ctx.slope) if ctx.slope != 1.0 else gy
+        gx = ga = gb = gns = gr = None
+        if _need(ctx, 0):
+            gx = ChanScaleFn.apply(gz, a) if a is not None else gz
+        if a is not None and _need(ctx, 1):
+            ga = ChanDotFn.apply(gz, x, a.numel() != x.shape[1]).reshape(a.shape).to(a.dtype)
+        if b is not None and _need(ctx, 2):
+            gb = ChanSumFn.apply(gz, False).reshape(b.shape).to(b.dtype)
+        if ns is not None and _need(ctx, 4):
+            gns = PixelDotFn.apply(gz, noise).reshape(ns.shape).to(ns.dtype)
+        if r is not None and _need(ctx, 5):
+            gr = gz.to(r.dtype)
+        return gx, ga, gb, None, gns, gr, None
+
+
+# ======================================================================================
+# functional API
+# ======================================================================================
+def upfirdn2d(imgs: Tensor, kernel: Tensor, up: int, down: int, px1: int, px2: int, py1: int, py2: int) -> Tensor:
+    return UpFirDnFn.apply(imgs, kernel, up, down, px1, px2, py1, py2)
+
+
+def _ones_taps(x: Tensor, value: float) -> Tensor:
+    return torch.full((2, 2), value, dtype=torch.float32, device=x.device)
+
+
+def nearest_up2(x: Tensor) -> Tensor:
+    """nn.Upsample(scale_factor=2.0) as upfirdn2d(ones(2,2), up=2, pads (1,0,1,0))."""
+    return UpFirDnFn.apply(x, _ones_taps(x, 1.0), 2, 1, 1, 0, 1, 0)
+
+
+def avg_pool2(x: Tensor) -> Tensor:
+    """nn.AvgPool2d(2) as upfirdn2d(ones(2,2)/4, down=2, no pad)."""
+    return UpFirDnFn.apply(x, _ones_taps(x, 0.25), 1, 2, 0, 0, 0, 0)
+
+
+def leaky_relu(x: Tensor, slope: float = 0.2) -> Tensor:
+    return LreluFn.apply(x, slope)
+
+
+def bias_leaky_relu(x: Tensor, bias: Optional[Tensor], slope: float = 0.2) -> Tensor:
+    """Fused lrelu(x + bias[c]): the op north_star names; oracle = F.leaky_relu(x + b.view(1,-1,1,1), 0.2)."""
+    return AffineActFn.apply(x, None, bias, None, None, None, slope)
+
+
+def affine_act(x, a=None, b=None, noise=None, ns=None, r=None, slope: float = 1.0) -> Tensor:
+    return AffineActFn.apply(x, a, b, noise, ns, r, slope)
+
+
+def conv2d(x: Tensor, weight: Tensor, padding: int = 0) -> Tensor:
+    return Conv2dFn.apply(x, weight, padding, padding)
+
+
+def act_dtype(x: Tensor) -> torch.dtype:
+    """Compute dtype of the kernels: the autocast dtype when autocast is on (train_celeba.py:92), else x's."""
+    if torch.is_autocast_enabled("cuda") if hasattr(torch, "is_autocast_enabled") else False:
+        return torch.get_autocast_dtype("cuda")
+    return x.dtype
+
+
+class ConvBiasActFn(Function):
+    """lrelu_slope(conv(x, W) + b) with bias and activation applied to the MFMA accumulators (one
+    launch, one store).  Replaces nn.Conv2d -> nn.LeakyReLU (progressive_gan.py:45-46,72-73).
+    Backward = mask_mul -> dgrad / wgrad / channel sum, all differentiable again."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, pad, slope):
+        y = raw_conv2d(x, weight, pad, pad, bias=bias, slope=slope)
+        ctx.save_for_backward(x, weight, bias, y)
+        ctx.pad, ctx.slope = pad, slope
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, bias, y = ctx.saved_tensors
+        pad, slope = ctx.pad, ctx.slope
+        gz = MaskMulFn.apply(gy, y, slope) if slope != 1.0 else gy
+        gx = Conv2dDgradFn.apply(gz, weight, pad, pad) if _need(ctx, 0) else None
+        gw = Conv2dWgradFn.apply(x, gz, weight.shape[2], weight.shape[3], pad, pad).to(weight.dtype) if _need(ctx, 1) else None
+        gb = None
+        if bias is not None and _need(ctx, 2):
+            gb = ChanSumFn.apply(gz, False).reshape(bias.shape).to(bias.dtype)
+        return gx, gw, gb, None, None
+
+
+def conv_bias_act(x: Tensor, weight: Tensor, bias: Optional[Tensor], padding: int, slope: float = 1.0) -> Tensor:
+    return ConvBiasActFn.apply(x, weight, bias, padding, slope)
+
+
+def minibatch_stddev_stat(x: Tensor, group: int) -> Tensor:
+    """(N/G,) fp32 statistic of MinibatchStdDev (progressive_gan.py:25-36).  The tensor is (N, 512, 4, 4):
+    8 K values per sample, differentiated to second order by R1 -- computed here with a handful of
+    fp32 tensor ops on that tiny tensor (the HIP forward kernel gan_mbstd_fwd serves no-grad calls)."""
+    n, c, h, w = x.shape
+    if not torch.is_grad_enabled() or not x.requires_grad:
+        return raw_mbstd_stat(x, group)
+    xf = x.float().reshape(group, n // group, c, h, w)
+    dev = xf - xf.mean(dim=0, keepdim=True)
+    std = (dev.square().sum(dim=0) / group + 1e-6).sqrt()
+    return std.mean(dim=(1, 2, 3))

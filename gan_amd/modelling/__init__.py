@@ -1,0 +1,21 @@
+"""Model registry (reference: modelling/__init__.py:15-45): same function names, same keys for the
+models on the StyleGAN2 / DCGAN hot path; unknown names raise KeyError like the reference's dict lookup."""
+from .dcgan import DcGanDiscriminator, DcGanGenerator
+from .progressive_gan import ProgressiveGanDiscriminator
+from .stylegan2 import StyleGan2Generator
+
+_GENERATORS = dict(dcgan=DcGanGenerator, stylegan2=StyleGan2Generator)
+_DISCRIMINATORS = dict(
+    dcgan=DcGanDiscriminator,
+    progressive_gan=ProgressiveGanDiscriminator,
+    stylegan=ProgressiveGanDiscriminator,
+    stylegan2=ProgressiveGanDiscriminator,
+)
+
+
+def build_generator(name: str, *args, **kwargs):
+    return _GENERATORS[name](*args, **kwargs)
+
+
+def build_discriminator(name: str, *args, **kwargs):
+    return _DISCRIMINATORS[name](*args, **kwargs)

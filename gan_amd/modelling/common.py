@@ -1,0 +1,127 @@
+"""Leaf modules with the reference's names, constructor signatures and state_dict keys, computing on
+the HIP kernels.  Reference: modelling/common.py:27-70 plus the stock torch.nn layers the reference's
+StyleGAN2 path instantiates (nn.Conv2d, nn.LeakyReLU, nn.AvgPool2d, nn.Upsample)."""
+from __future__ import annotations
+
+from functools import partial
+
+import torch
+from torch import Tensor, nn
+
+from .. import functional as GF
+
+
+def to_act(x: Tensor) -> Tensor:
+    """Cast to the kernels' compute dtype (autocast dtype if autocast is on) and channels-last."""
+    if x.dim() != 4:
+        raise GF._lib.GanAmdError(f"expected a 4-D (N, C, H, W) tensor, got shape {tuple(x.shape)}")
+    dt = GF.act_dtype(x)
+    if dt not in (torch.float32, torch.bfloat16):
+        raise GF._lib.GanAmdError(f"unsupported compute dtype {dt}: the kernels take float32 or bfloat16")
+    if x.dtype != dt:
+        x = x.to(dt)
+    return x.contiguous(memory_format=torch.channels_last)
+
+
+class Conv2d(nn.Conv2d):
+    """nn.Conv2d (stride 1, dilation 1, groups 1, zero padding) on the MFMA implicit-GEMM kernel."""
+
+    def _check(self):
+        if self.stride != (1, 1) or self.dilation != (1, 1) or self.groups != 1 or self.padding_mode != "zeros":
+            raise GF._lib.GanAmdError("gan_amd Conv2d supports stride 1, dilation 1, groups 1, zero padding")
+        if isinstance(self.padding, str):
+            raise GF._lib.GanAmdError("gan_amd Conv2d takes integer padding")
+
+    def forward(self, x: Tensor) -> Tensor:
+        self._check()
+        x = to_act(x)
+        y = GF.Conv2dFn.apply(x, self.weight, self.padding[0], self.padding[1])
+        if self.bias is not None:
+            y = GF.affine_act(y, b=self.bias)
+        return y
+
+
+class LeakyReLU(nn.LeakyReLU):
+    """Always out of place: the reference's inplace=True breaks autograd in the D block;
+    forward values are identical."""
+
+    def forward(self, x: Tensor) -> Tensor:
+        return GF.leaky_relu(to_act(x), self.negative_slope)
+
+
+class AvgPool2d(nn.AvgPool2d):
+    def forward(self, x: Tensor) -> Tensor:
+        if self.kernel_size not in (2, (2, 2)):
+            raise GF._lib.GanAmdError("gan_amd AvgPool2d supports kernel_size=2")
+        return GF.avg_pool2(to_act(x))
+
+
+class Upsample(nn.Upsample):
+    def forward(self, x: Tensor) -> Tensor:
+        if self.scale_factor not in (2, 2.0) or self.mode != "nearest":
+            raise GF._lib.GanAmdError("gan_amd Upsample supports nearest x2")
+        return GF.nearest_up2(to_act(x))
+
+
+def get_norm(norm: str, dim: int):
+    """modelling/common.py:27-33 -- only the entries the hot path uses ("none" for the StyleGAN2/DCGAN D)."""
+    return dict(none=nn.Identity, batch=partial(nn.BatchNorm2d, track_running_stats=False))[norm](dim)
+
+
+def get_act(act: str):
+    """modelling/common.py:36-43."""
+    return dict(none=nn.Identity, relu=nn.ReLU, leaky_relu=partial(LeakyReLU, negative_slope=0.2), tanh=nn.Tanh)[act]()
+
+
+class _StridedConv2d(nn.Conv2d):
+    """Conv2d(stride 2) as a stride-1 MFMA correlation followed by keeping every second sample."""
+
+    def forward(self, x: Tensor) -> Tensor:
+        if self.stride == (1, 1):
+            return Conv2d.forward(self, x)
+        if self.stride != (2, 2):
+            raise GF._lib.GanAmdError("gan_amd strided Conv2d supports stride 1 or 2")
+        x = to_act(x)
+        y = GF.Conv2dFn.apply(x, self.weight, self.padding[0], self.padding[1])
+        y = GF.upfirdn2d(y, torch.ones(1, 1, device=x.device), 1, 2, 0, 0, 0, 0)
+        return GF.affine_act(y, b=self.bias) if self.bias is not None else y
+
+    _check = Conv2d._check
+
+
+class _ConvTranspose2d(nn.ConvTranspose2d):
+    """ConvTranspose2d (stride 1 or 2) = zero insertion (upfirdn2d with a unit tap) + stride-1
+    correlation with the transposed, flipped weights."""
+
+    def forward(self, x: Tensor) -> Tensor:
+        k, p, op, st = self.kernel_size[0], self.padding[0], self.output_padding[0], self.stride[0]
+        if st not in (1, 2) or self.groups != 1 or self.dilation != (1, 1):
+            raise GF._lib.GanAmdError("gan_amd ConvTranspose2d supports stride 1 or 2, groups 1, dilation 1")
+        x = to_act(x)
+        full = k - 1 - p
+        if st == 2:
+            x = GF.upfirdn2d(x, torch.ones(1, 1, device=x.device), 2, 1, full, full - 1 + op, full, full - 1 + op)
+            full = 0
+        w = self.weight.flip(2, 3).transpose(0, 1)
+        y = GF.Conv2dFn.apply(x, w, full, full)
+        return GF.affine_act(y, b=self.bias) if self.bias is not None else y
+
+
+def conv_norm_act(
+    in_dim: int,
+    out_dim: int,
+    kernel_size: int,
+    stride: int = 1,
+    *,
+    transpose: bool = False,
+    padding_mode: str = "zeros",
+    norm: str = "none",
+    act: str = "none",
+) -> nn.Sequential:
+    """modelling/common.py:46-70."""
+    conv_cls = _ConvTranspose2d if transpose else _StridedConv2d
+    return nn.Sequential(
+        conv_cls(in_dim, out_dim, kernel_size, stride, (kernel_size - 1) // 2, bias=norm in ("none", "layer"), padding_mode=padding_mode),
+        get_norm(norm, out_dim),
+        get_act(act),
+    )

@@ -1,0 +1,112 @@
+"""The StyleGAN2 discriminator (modelling/__init__.py:37 maps "stylegan2" to ProgressiveGanDiscriminator).
+
+Reference: modelling/progressive_gan.py:20-82,136-140 -- same class names, constructor signatures,
+child-module layout and state_dict keys.  Every convolution, leaky-ReLU, pooling and residual op runs
+on the HIP kernels through Functions whose backward is again made of those kernels, so the R1 /
+WGAN-GP double backward (losses.py:89-103) never differentiates through PyTorch ops' autograd.
+
+Fusions per block (progressive_gan.py:43-54):  bias + LeakyReLU ride behind the first conv in one
+pass; conv biases that precede AvgPool2d are added after it (avg_pool(z + b) = avg_pool(z) + b) and
+folded, together with the shortcut's bias and the per-channel `scale`, into the single residual pass
+    out = shortcut_conv + pooled * scale + (b_short + b2 * scale).
+LeakyReLU is applied out of place (the shipped inplace=True breaks autograd).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+from torch import Tensor, nn
+
+from .. import functional as GF
+from .common import AvgPool2d, Conv2d, LeakyReLU, to_act
+
+
+class MinibatchStdDev(nn.Module):
+    def __init__(self, group_size: int = 4) -> None:
+        super().__init__()
+        self.group_size = group_size
+
+    def forward(self, imgs: Tensor) -> Tensor:
+        """(N, C, H, W) -> (N, C+1, H, W); groups are {j + k*N/G} (progressive_gan.py:27), population
+        variance, eps 1e-6 inside the sqrt, mean over (C, H, W)."""
+        imgs = to_act(imgs)
+        n, c, h, w = imgs.shape
+        if n % self.group_size != 0:
+            raise GF._lib.GanAmdError(f"MinibatchStdDev: batch {n} is not a multiple of group_size {self.group_size}")
+        stat = GF.minibatch_stddev_stat(imgs, self.group_size)  # (N/G,) fp32
+        plane = stat.repeat(self.group_size).to(imgs.dtype).view(n, 1, 1, 1).expand(n, 1, h, w)
+        return torch.cat([imgs, plane], dim=1).contiguous(memory_format=torch.channels_last)
+
+
+class ProgressiveGanDiscriminatorBlock(nn.Module):
+    def __init__(self, in_dim: int, out_dim: int) -> None:
+        super().__init__()
+        self.layers = nn.Sequential(
+            LeakyReLU(0.2),
+            Conv2d(in_dim, in_dim, 3, 1, 1),
+            LeakyReLU(0.2),
+            Conv2d(in_dim, out_dim, 3, 1, 1),
+            AvgPool2d(2),
+        )
+        self.shortcut = nn.Sequential(AvgPool2d(2), Conv2d(in_dim, out_dim, 1))
+        self.scale = nn.Parameter(torch.full((out_dim, 1, 1), 1e-4))
+
+    def forward(self, x: Tensor) -> Tensor:
+        x = to_act(x)
+        act0, conv1, act1, conv2, _ = self.layers
+        conv_s = self.shortcut[1]
+        h = GF.leaky_relu(x, act0.negative_slope)
+        h = GF.conv_bias_act(h, conv1.weight, conv1.bias, conv1.padding[0], act1.negative_slope)
+        h = GF.Conv2dFn.apply(h, conv2.weight, conv2.padding[0], conv2.padding[1])
+        h = GF.avg_pool2(h)
+        s = GF.Conv2dFn.apply(GF.avg_pool2(x), conv_s.weight, 0, 0)
+        scale = self.scale.reshape(-1)
+        bias = conv_s.bias + conv2.bias * scale  # (Cout,) -- three tiny vectors
+        return GF.affine_act(h, a=scale, b=bias, r=s)
+
+
+class ProgressiveGanDiscriminator(nn.Sequential):
+    def __init__(self, img_size: int, img_channels: int = 3, base_dim: int = 16) -> None:
+        super().__init__()
+        depth = int(math.log2(img_size // 4))
+        self.append(Conv2d(img_channels, base_dim, 1))
+        in_ch = base_dim
+
+        for _ in range(depth):
+            out_ch = min(in_ch * 2, 512)
+            self.append(ProgressiveGanDiscriminatorBlock(in_ch, out_ch))
+            in_ch = out_ch
+
+        self.append(
+            nn.Sequential(
+                MinibatchStdDev(),
+                Conv2d(in_ch + 1, in_ch, 3, 1, 1),
+                LeakyReLU(0.2),
+                Conv2d(in_ch, 1, 4),
+                nn.Flatten(0),
+            )
+        )
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        self.apply(init_weights)
+
+    def forward(self, imgs: Tensor) -> Tensor:
+        x = to_act(imgs)
+        *body, head = list(self)
+        for m in body:
+            x = m(x)
+        mbstd, conv1, act, conv2, flat = head
+        x = mbstd(x)
+        x = GF.conv_bias_act(x, conv1.weight, conv1.bias, conv1.padding[0], act.negative_slope)
+        x = conv2(x)
+        return flat(x).float()
+
+
+def init_weights(module: nn.Module):
+    """kaiming-normal weights, zero biases on every conv / linear (progressive_gan.py:136-140)."""
+    if isinstance(module, (nn.modules.conv._ConvNd, nn.Linear)):
+        nn.init.kaiming_normal_(module.weight)
+        if module.bias is not None:
+            nn.init.zeros_(module.bias)

@@ -1,0 +1,226 @@
+"""StyleGAN2 generator on the MFMA modulated-convolution kernel.
+
+Reference: modelling/stylegan2.py (same class names, constructor signatures, forward signatures and
+state_dict keys).  What differs is how the arithmetic is organised for MI355X:
+
+* ModulatedConv2d never materialises the per-sample weights W[n] = W * s[n] / ||W * s[n]|| that the
+  reference builds (stylegan2.py:30-33).  The identical result is computed as
+      y[n] = dinv[n, co] * conv(x[n] * s[n, ci], W) + b,
+      dinv[n, co] = 1 / max( sqrt( sum_ci s[n,ci]^2 * sum_k W[co,ci,k]^2 ), 1e-8 )
+  i.e. one shared-weight implicit GEMM (bf16 MFMA, fp32 accumulate) with the modulation applied to
+  the activation tile while it is staged into LDS, and demodulation + bias + noise + leaky-ReLU
+  applied to the accumulators before the single store (kernel gan_conv2d_fwd).
+* nn.Upsample(2) in front of a block's first conv (stylegan2.py:45) is folded into that conv's
+  input gather (`up2`): the 4x larger tensor is never written.
+* `to_rgb(x, w_embs)`: the shipped block calls `self.to_rgb(x)` without the style (stylegan2.py:64,
+  a TypeError); the intended call is implemented.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+from torch import Tensor, nn
+from torch.autograd import Function
+
+from .. import functional as GF
+from .common import LeakyReLU, Upsample, to_act
+from .progressive_gan import init_weights
+from .stylegan import Noise
+
+
+class ModConvFn(Function):
+    """y = lrelu_slope( dinv * conv(U(x) * s, W) + b + noise * ns ),  U = nearest x2 if up2.
+
+    Forward: one fused kernel.  Backward without create_graph: hand-written kernels (leaky-ReLU
+    mask + demod scale in one pass, channel reductions for b / ns / dinv, dgrad, wgrad with the
+    modulation fused into its operand staging).  Backward under create_graph: the same forward is
+    re-expressed through the differentiable primitives of gan_amd.functional and differentiated, so
+    any order of gradient stays on the HIP kernels."""
+
+    @staticmethod
+    def forward(ctx, x, weight, s, dinv, bias, noise, ns, slope, up2):
+        pad = (weight.shape[2] - 1) // 2
+        y = GF.raw_conv2d(
+            x, weight, pad, pad, up2=up2, in_scale=s, out_scale=dinv, bias=bias, noise=noise, noise_scale=ns, slope=slope
+        )
+        ctx.save_for_backward(x, weight, s, dinv, bias, noise, ns, y)
+        ctx.slope, ctx.up2, ctx.pad = slope, up2, pad
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, s, dinv, bias, noise, ns, y = ctx.saved_tensors
+        slope, up2, pad = ctx.slope, ctx.up2, ctx.pad
+        if torch.is_grad_enabled():
+            return ModConvFn._backward_differentiable(ctx, gy)
+        need = ctx.needs_input_grad
+        gy = GF.as_cl(gy)
+        n, cout = gy.shape[0], gy.shape[1]
+        kh = weight.shape[2]
+        # ---- epilogue gradients: channel reductions over gy, masked by the activation output ----
+        gb = gns = gdinv = None
+        mask = y if slope != 1.0 else None
+        want_dinv = dinv is not None and need[3]
+        t1 = t2 = None
+        if bias is not None and (need[4] or want_dinv):
+            t1 = GF.raw_chan_dot(gy, None, 0, mask, slope, True)  # sum_hw gy*m(y)  -> (N, Cout)
+            if need[4]:
+                gb = t1.sum(0).reshape(bias.shape).to(bias.dtype)
+        if ns is not None and (need[6] or want_dinv):
+            t2 = GF.raw_chan_dot(gy, noise, 2, mask, slope, True)  # sum_hw gy*m(y)*noise
+            if need[6]:
+                gns = t2.sum(0).reshape(ns.shape).to(ns.dtype)
+        if want_dinv:
+            # z*dinv = lrelu^-1(y) - b - noise*ns   and   gy*m(y)*lrelu^-1(y) = gy*y
+            acc = GF.raw_chan_dot(gy, y, 1, None, 1.0, True)
+            if t1 is not None:
+                acc = acc - t1 * bias.detach().float().reshape(1, -1)
+            if t2 is not None:
+                acc = acc - t2 * ns.detach().float().reshape(1, -1)
+            gdinv = (acc / dinv.detach().float()).reshape(dinv.shape).to(dinv.dtype)
+        # ---- gz = gy * m(y) * dinv: the gradient entering the shared-weight convolution ----------
+        gz = GF.raw_mask_scale(gy, y if slope != 1.0 else None, dinv, slope)
+        gx = gw = gs = None
+        if need[0] or need[2]:
+            gxs = GF.raw_conv2d_dgrad(gz, weight, pad, pad)  # d/d(U(x)*s), at the conv's input resolution
+            if up2:  # adjoint of nearest x2: sum each 2x2 block
+                h2, w2 = gxs.shape[2], gxs.shape[3]
+                gxs = GF.raw_upfirdn2d(gxs, torch.ones(2, 2, device=gxs.device), 1, 2, 0, 0, h2 // 2, w2 // 2)
+            if need[2]:
+                gs = GF.raw_chan_dot(gxs, x, 1, None, 1.0, True).reshape(s.shape).to(s.dtype)
+            if need[0]:
+                gx = GF.raw_mask_scale(gxs, None, s, 1.0)
+        if need[1]:
+            gw = GF.raw_conv2d_wgrad(x, gz, kh, kh, pad, pad, up2=up2, in_scale=s).to(weight.dtype)
+        return gx, gw, gs, gdinv, gb, None, gns, None, None
+
+    @staticmethod
+    def _backward_differentiable(ctx, gy):
+        x, weight, s, dinv, bias, noise, ns, y = ctx.saved_tensors
+        slope, up2, pad = ctx.slope, ctx.up2, ctx.pad
+        with torch.enable_grad():
+            xu = GF.nearest_up2(x) if up2 else x
+            xs = GF.ChanScaleFn.apply(xu, s)
+            z = GF.Conv2dFn.apply(xs, weight, pad, pad)
+            y2 = GF.AffineActFn.apply(z, dinv, bias, noise, ns, None, slope)
+            inputs, slots = [], []
+            for i, t in enumerate((x, weight, s, dinv, bias, None, ns)):
+                if t is not None and ctx.needs_input_grad[i]:
+                    inputs.append(t)
+                    slots.append(i)
+            grads = torch.autograd.grad(y2, inputs, gy, create_graph=True, allow_unused=True)
+        out = [None] * 9
+        for i, g in zip(slots, grads):
+            out[i] = g
+        return tuple(out)
+
+
+class ModulatedConv2d(nn.Conv2d):
+    def __init__(self, in_channels: int, out_channels: int, kernel_size: int, z_dim: int, demodulation: bool = True) -> None:
+        super().__init__(in_channels, out_channels, kernel_size, padding=(kernel_size - 1) // 2)
+        self.style_weight = nn.Linear(z_dim, in_channels)  # A in the paper
+        self.demodulation = demodulation
+
+    def style_and_demod(self, w: Tensor):
+        """s = A(w) + 1 (stylegan2.py:30) and the demodulation factor of F.normalize(dim=(2,3,4),
+        eps=1e-8) (stylegan2.py:33), both in fp32: two tiny GEMMs instead of an (N,Cout,Cin,k,k) tensor."""
+        with torch.autocast("cuda", enabled=False):
+            s = F.linear(w.float(), self.style_weight.weight, self.style_weight.bias) + 1  # (N, Cin)
+            dinv = None
+            if self.demodulation:
+                wsq = self.weight.float().square().sum(dim=(2, 3))  # (Cout, Cin)
+                dinv = 1.0 / (s.square() @ wsq.t()).sqrt().clamp_min(1e-8)  # (N, Cout)
+        return s, dinv
+
+    def fused(self, x: Tensor, w: Tensor, noise: Optional[Tensor], noise_scale: Optional[Tensor], slope: float, up2: bool):
+        x = to_act(x)
+        s, dinv = self.style_and_demod(w)
+        return ModConvFn.apply(x, self.weight, s, dinv, self.bias, noise, noise_scale, slope, up2)
+
+    def forward(self, x: Tensor, w: Tensor) -> Tensor:
+        return self.fused(x, w, None, None, 1.0, False)
+
+
+class StyleGan2GeneratorBlock(nn.Module):
+    def __init__(self, in_dim: int, out_dim: int, z_dim: int, img_channels: int, first_block: bool = False) -> None:
+        super().__init__()
+        self.layers = nn.ModuleList()
+        if not first_block:
+            self.layers.extend(
+                [Upsample(scale_factor=2.0), ModulatedConv2d(in_dim, out_dim, 3, z_dim), Noise(out_dim), LeakyReLU(0.2)]
+            )
+        self.layers.extend([ModulatedConv2d(out_dim, out_dim, 3, z_dim), Noise(out_dim), LeakyReLU(0.2)])
+        self.to_rgb = ModulatedConv2d(out_dim, img_channels, 1, z_dim, demodulation=False)
+
+    def forward(self, x: Tensor, w_embs: Tensor):
+        """Walks self.layers like the reference (stylegan2.py:61-64) but hands each
+        [Upsample?, ModulatedConv2d, Noise, LeakyReLU] group to ONE fused kernel launch."""
+        layers = list(self.layers)
+        i = 0
+        x = to_act(x)
+        while i < len(layers):
+            up2 = False
+            if isinstance(layers[i], Upsample):
+                up2 = True
+                i += 1
+            conv = layers[i]
+            if (
+                isinstance(conv, ModulatedConv2d)
+                and i + 2 < len(layers)
+                and isinstance(layers[i + 1], Noise)
+                and isinstance(layers[i + 2], LeakyReLU)
+            ):
+                noise_mod, act = layers[i + 1], layers[i + 2]
+                n, _, h, w = x.shape
+                ho, wo = (2 * h, 2 * w) if up2 else (h, w)
+                # one draw per Noise forward, same shape/dtype/order as the reference (stylegan.py:26)
+                draw = torch.randn(n, 1, ho, wo, device=x.device, dtype=x.dtype)
+                x = conv.fused(x, w_embs, draw, noise_mod.scale, act.negative_slope, up2)
+                i += 3
+            else:  # unfused fallback for a re-arranged ModuleList: same ops, one launch each
+                if up2:
+                    x = GF.nearest_up2(x)
+                x = conv(x, w_embs) if isinstance(conv, ModulatedConv2d) else conv(x)
+                i += 1
+        return x, self.to_rgb(x, w_embs)
+
+
+class StyleGan2Generator(nn.Module):
+    def __init__(self, img_size: int, img_channels: int = 3, z_dim: int = 128, base_dim: int = 16) -> None:
+        super().__init__()
+        self.mapping_network = nn.Sequential(nn.LayerNorm(z_dim))
+        for _ in range(8):
+            self.mapping_network.extend([nn.Linear(z_dim, z_dim), nn.LeakyReLU(0.2)])
+
+        self.learned_input = nn.Parameter(torch.ones(1, 512, 4, 4))
+
+        out_ch = min(base_dim * img_size // 4, 512)
+        self.blocks = nn.ModuleList()
+        self.blocks.append(StyleGan2GeneratorBlock(512, out_ch, z_dim, img_channels, first_block=True))
+        in_ch = out_ch
+
+        depth = int(math.log2(img_size // 4))
+        for i in range(depth):
+            out_ch = min(base_dim * img_size // 4 // 2 ** (i + 1), 512)
+            self.blocks.append(StyleGan2GeneratorBlock(in_ch, out_ch, z_dim, img_channels))
+            in_ch = out_ch
+
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        self.apply(init_weights)
+
+    def forward(self, z: Tensor) -> Tensor:
+        # mapping network: 8 x (128x128 Linear + LeakyReLU) on (N,128) -- plain library GEMMs (hipBLASLt)
+        w = self.mapping_network(z)
+        dt = GF.act_dtype(z)
+        x = self.learned_input.to(dt).expand(z.shape[0], -1, -1, -1)
+        x, y = self.blocks[0](x, w)
+        for block in self.blocks[1:]:
+            x, new_y = block(x, w)
+            # RGB skip: y = upsample(y) + new_y (stylegan2.py:99) in one fused pass
+            y = GF.affine_act(GF.nearest_up2(y), r=new_y)
+        return y

@@ -1,0 +1,121 @@
+/*
+ * gan_amd.h -- C ABI of libgan_amd.so: hand-written HIP kernels (gfx950 / MI355X) for the
+ * StyleGAN2 training hot path of gau-nernst/gan.
+ *
+ * The reference has no FFI; its operator boundary is the Python module API.
+ * Each entry point below is what the Python autograd.Functions of `gan_amd` bind through
+ * ctypes, and cites the reference code (file:line under /root/reference) whose arithmetic it
+ * replaces.
+ *
+ * Conventions
+ *  - All tensors are device pointers.  Activations are channels-last: [N][H][W][C], C fastest.
+ *  - `dtype` selects the activation element type: GAN_F32 (float) or GAN_BF16 (bfloat16).
+ *    Accumulation is always fp32.  Per-channel / per-sample side vectors (bias, scales, FIR
+ *    taps, reductions, weight gradients) are always fp32.
+ *  - The caller allocates every output.  The library never allocates, frees or synchronises;
+ *    kernels are enqueued on `stream` (a hipStream_t) and the call returns immediately.
+ *  - Return value: 0 on success, negative on error; gan_amd_last_error() then describes it
+ *    (thread-local).  Nothing is launched when an argument check fails.
+ *  - One process per GPU; calls are re-entrant; there is no global mutable state.
+ */
+#ifndef GAN_AMD_H
+#define GAN_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GAN_F32 0
+#define GAN_BF16 1
+
+#define GAN_OK 0
+#define GAN_ERR_ARG (-1)
+#define GAN_ERR_LAUNCH (-2)
+
+typedef void* gan_stream_t; /* hipStream_t */
+
+/* ---- probes ---------------------------------------------------------------------------- */
+int gan_amd_version(void);            /* ABI version, bumped on any signature change          */
+const char* gan_amd_arch(void);       /* "gfx950"                                             */
+const char* gan_amd_last_error(void); /* message of the last failing call on this thread      */
+
+/* ---- upfirdn2d -------------------------------------------------------------------------
+ * replaces upfirdn2d()            modelling/nvidia_ops.py:18-34
+ *          UpFIRDn2d fwd/bwd      modelling/nvidia_ops.py:40-54 (backward = same entry, swapped args)
+ *          nn.Upsample(2) / F.upsample / nn.AvgPool2d(2) as special cases
+ *                                 modelling/stylegan2.py:45,99  modelling/progressive_gan.py:48,50
+ * y[n,oy,ox,c] = sum_{i,j} taps[i*kx+j] * P[n, oy*down+i, ox*down+j, c], P = zero-insert(x, up)
+ * padded by (px1,px2,py1,py2) (negative pad crops); taps are NOT flipped (correlation).
+ * x: [N][H][W][C], y: [N][Ho][Wo][C], taps: fp32 [ky*kx] on the device.
+ * Ho/Wo are passed by the caller (reference formula (H*up+py1+py2-ky)/down+1; the backward
+ * passes the forward's input size, see gan_amd/modelling/nvidia_ops.py). */
+int gan_upfirdn2d(const void* x, const float* taps, void* y, int N, int H, int W, int C, int ky, int kx, int up,
+                  int down, int px1, int py1, int Ho, int Wo, int dtype, gan_stream_t stream);
+
+/* ---- fused channel-affine + noise + residual + leaky-ReLU ---------------------------------
+ * replaces the unfused sequence  conv bias (stylegan2.py:35) -> Noise (stylegan.py:24-27) ->
+ *          LeakyReLU(0.2) (stylegan2.py:49,56; progressive_gan.py:44,46,73), the demodulation
+ *          scale of ModulatedConv2d (stylegan2.py:33) and the residual `shortcut + layers*scale`
+ *          (progressive_gan.py:54).  No gain, no clamp.
+ * y = lrelu_slope( x*a[n*a_stride_n + c] + b[c] + noise[n,hw]*ns[c] + r[n,hw,c] )
+ * Any of a, b, noise/ns, r may be NULL (term dropped).  slope = 1 gives a linear op.
+ * x, r, y: [N][HW][C]; noise: [N][HW] (same dtype as x); a, b, ns: fp32. */
+int gan_affine_act_fwd(const void* x, const float* a, int64_t a_stride_n, const float* b, const void* noise,
+                       const float* ns, const void* r, void* y, int N, int64_t HW, int C, float slope, int dtype,
+                       gan_stream_t stream);
+
+/* Backward building block of the op above (and, applied twice, its double backward):
+ * out = g * m(ymask) * a[n*a_stride_n + c],  m(v) = v > 0 ? 1 : slope   (mask from the OUTPUT
+ * of the activation: sign(y) == sign(pre-activation) for slope > 0).  ymask, a may be NULL. */
+int gan_mask_scale(const void* g, const void* ymask, const float* a, int64_t a_stride_n, void* out, int N,
+                   int64_t HW, int C, float slope, int dtype, gan_stream_t stream);
+
+/* Channel reductions for bias / noise-scale / style / demodulation / D-block `scale` gradients
+ * (wavefront shuffle + LDS reduction, fp32 atomics across workgroups; `out` is zeroed here):
+ * out[n*out_stride_n + c] = sum_hw A[n,hw,c] * m(ymask[n,hw,c]) * Bterm,
+ *   Bterm = B[n,hw,c] (b_mode 1), B[n,hw] broadcast over c (b_mode 2), or 1 (b_mode 0).
+ * out_stride_n = C gives per-sample sums [N][C]; out_stride_n = 0 gives batch sums [C]. */
+int gan_chan_dot(const void* A, const void* B, int b_mode, const void* ymask, float slope, float* out,
+                 int64_t out_stride_n, int N, int64_t HW, int C, int dtype, gan_stream_t stream);
+
+/* ---- implicit-GEMM convolution (MFMA) ----------------------------------------------------
+ * replaces ModulatedConv2d.forward / batched_conv2d   modelling/stylegan2.py:18-36
+ *          nn.Conv2d of the discriminator             modelling/progressive_gan.py:45-50,61,72,74
+ *          and, with transposed/flipped weights, their input gradients (autograd of the above).
+ * y[n,oy,ox,co] = act( out_scale[n,co] * sum_{dy,dx,ci} X[n,oy+dy-py,ox+dx-px,ci] * in_scale[n,ci]
+ *                       * Wt[co][(dy*kw+dx)*Cin+ci] + bias[co] + noise[n,oy,ox]*noise_scale[co] )
+ * X = x, or nearest-neighbour 2x upsampling of x when up2 != 0 (stylegan2.py:45 fused into the gather).
+ * Stride 1.  x: [N][H][W][Cin] with Cin % 8 == 0; wt: [Cout][Kpad] in the activation dtype,
+ * K index = tap*Cin + ci, zero-padded to Kpad (multiple of 32, >= kh*kw*Cin);
+ * y: [N][Ho][Wo][Cout]; in_scale [N][Cin], out_scale [N][Cout], bias/noise_scale [Cout] fp32 or NULL;
+ * noise [N][Ho*Wo] in the activation dtype or NULL; slope = 1 for no activation. */
+int gan_conv2d_fwd(const void* x, const void* wt, void* y, const float* in_scale, const float* out_scale,
+                   const float* bias, const void* noise, const float* noise_scale, float slope, int N, int H, int W,
+                   int Cin, int up2, int Ho, int Wo, int Cout, int kh, int kw, int py, int px, int Kpad, int dtype,
+                   gan_stream_t stream);
+
+/* Weight gradient (autograd of the convolutions above):
+ * dw[tap][co][ci] = sum_{n,oy,ox} gy[n,oy,ox,co] * X[n,oy+dy-py,ox+dx-px,ci] * in_scale[n,ci]
+ * dw: fp32 [kh*kw][Cout][Cin], zeroed here, accumulated with fp32 atomics over pixel splits.
+ * Cin % 16 == 0 and Cout % 16 == 0 (callers pad). */
+int gan_conv2d_wgrad(const void* x, const void* gy, float* dw, const float* in_scale, int N, int H, int W, int Cin,
+                     int up2, int Ho, int Wo, int Cout, int kh, int kw, int py, int px, int dtype,
+                     gan_stream_t stream);
+
+/* ---- MinibatchStdDev ---------------------------------------------------------------------
+ * replaces MinibatchStdDev.forward   modelling/progressive_gan.py:20-36
+ * stat[j] = mean_{c,h,w} sqrt( var_k x[j + k*M] + 1e-6 ),  M = N/G, population variance over the
+ * G group members.  x: [N][HW][C]; stat: fp32 [M] (zeroed here). */
+int gan_mbstd_fwd(const void* x, float* stat, int N, int G, int64_t HW, int C, int dtype, gan_stream_t stream);
+
+/* ---- EMA ---------------------------------------------------------------------------------
+ * replaces the per-parameter lerp_ loop of EMA.step   utils.py:95-96
+ * ema[i] += (p[i] - ema[i]) * weight over one flat fp32 arena. */
+int gan_ema_lerp(float* ema, const float* p, int64_t n, float weight, gan_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GAN_AMD_H */

@@ -1,0 +1,286 @@
+"""GPU parity of every HIP op (through the C ABI, via gan_amd.functional) against the oracle.
+
+Tolerances are BASELINE.json's: rel-err <= 1e-5 in fp32 and <= 1e-2 in bf16, forward and
+gradients (rel-err = ||a-b|| / ||b||); second-order quantities get 1e-4 in fp32.
+The oracle runs on the CPU (fp64 where cheap) on the same inputs."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL32, TOL32_2, TOLBF = 1e-5, 1e-4, 1e-2
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from gan_amd import _lib
+
+    _lib.load()
+    return torch.device("cuda:0")
+
+
+def test_library_probes(dev):
+    from gan_amd import _lib
+
+    lib = _lib.load()
+    assert lib.gan_amd_version() == _lib.ABI_VERSION
+    assert lib.gan_amd_arch() == b"gfx950"
+    # argument errors come back as exceptions with the library's message
+    import gan_amd.functional as GF
+
+    with pytest.raises(_lib.GanAmdError):
+        GF.raw_conv2d(torch.zeros(1, 8, 4, 4, device=dev), torch.zeros(8, 8, 3, 3, device=dev), 5, 5, noise=torch.zeros(1, 1, 12, 12, device=dev))
+    with pytest.raises(_lib.GanAmdError):
+        GF.raw_affine_act(torch.zeros(1, 8, 4, 4))  # CPU tensor: no CPU path
+
+
+# ------------------------------------------------------------------------------------------
+def test_upfirdn2d_golden(dev, golden):
+    from gan_amd.modelling.nvidia_ops import UpFIRDn2d, upfirdn2d
+
+    for case in golden("upfirdn2d")["cases"]:
+        x = case["x"].to(dev).requires_grad_(True)
+        k = case["kernel"].to(dev)
+        y = upfirdn2d(x, k, *case["args"])
+        assert y.shape == case["y"].shape
+        assert rel_err(y, case["y"]) < TOL32, case["args"]
+        y2 = UpFIRDn2d.apply(x, k, *case["args"])
+        assert torch.equal(y2, y)
+        (g1,) = torch.autograd.grad(y.square().sum(), x, create_graph=True)
+        assert rel_err(g1, case["g1"]) < TOL32, case["args"]
+        (g2,) = torch.autograd.grad(g1.square().sum(), x)
+        assert rel_err(g2, case["g2"]) < TOL32_2, case["args"]
+
+
+def test_upfirdn2d_blur_identities(dev, golden):
+    from gan_amd.modelling.nvidia_ops import Blur, upfirdn2d
+    import gan_amd.functional as GF
+
+    g = golden("upfirdn2d")
+    for k, ref in g["make_kernel"].items():
+        assert torch.equal(Blur.make_kernel(int(k)), ref)
+    with pytest.raises(AssertionError):
+        Blur.make_kernel(8)
+    x = g["identities"]["x"].to(dev)
+    assert torch.equal(GF.nearest_up2(x).cpu(), g["identities"]["nearest_up2"])
+    assert rel_err(GF.avg_pool2(x), g["identities"]["avg_pool2"]) < 1e-6
+    xb = g["blur"]["x"].to(dev)
+    for key, ref in g["blur"].items():
+        if key == "x":
+            continue
+        k, u, d = (int(p[1:]) for p in key.split("_"))
+        assert rel_err(Blur(k, u, d).to(dev)(xb), ref) < TOL32, key
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 9, 7), (1, 8, 32, 32), (3, 24, 5, 5), (2, 3, 8, 8), (2, 513, 4, 4)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_upfirdn2d_shapes_dtypes(dev, shape, dtype):
+    from oracle import gan_oracle as O
+    from gan_amd.modelling.nvidia_ops import upfirdn2d
+
+    torch.manual_seed(0)
+    for up, down, k, pads in [(1, 1, 3, (1, 1, 1, 1)), (2, 1, 4, (2, 1, 2, 1)), (1, 2, 4, (1, 2, 1, 2)), (2, 2, 3, (1, 1, 1, 1))]:
+        x = torch.randn(shape).to(dtype)
+        kern = torch.randn(k, k)
+        ref = O.upfirdn2d(x.double(), kern.double(), up, down, *pads)
+        got = upfirdn2d(x.to(dev), kern.to(dev), up, down, *pads)
+        assert got.dtype == dtype and got.shape == ref.shape
+        assert rel_err(got, ref) < (TOL32 if dtype == torch.float32 else TOLBF), (shape, up, down)
+
+
+def test_upfirdn2d_empty_and_ragged(dev):
+    from gan_amd.modelling.nvidia_ops import upfirdn2d
+    from gan_amd._lib import GanAmdError
+
+    k = torch.ones(3, 3, device=dev)
+    y = upfirdn2d(torch.zeros(0, 8, 4, 4, device=dev), k, 1, 1, 1, 1, 1, 1)  # empty batch
+    assert y.shape == (0, 8, 4, 4)
+    with pytest.raises(GanAmdError):
+        upfirdn2d(torch.zeros(1, 8, 2, 2, device=dev), torch.ones(7, 7, device=dev), 1, 1, 0, 0, 0, 0)  # empty output
+    with pytest.raises(GanAmdError):
+        upfirdn2d(torch.zeros(8, 4, 4, device=dev), k, 1, 1, 1, 1, 1, 1)  # not 4-D
+
+
+# ------------------------------------------------------------------------------------------
+def test_bias_leaky_relu_golden(dev, golden):
+    from gan_amd.modelling.nvidia_ops import bias_leaky_relu
+
+    b = golden("small_ops")["bias_lrelu"]
+    x = b["x"].to(dev).requires_grad_(True)
+    bias = b["b"].to(dev).requires_grad_(True)
+    y = bias_leaky_relu(x, bias)
+    assert rel_err(y, b["y"]) < TOL32
+    gx, gb = torch.autograd.grad(y.square().sum(), [x, bias], create_graph=True)
+    assert rel_err(gx, b["gx"]) < TOL32 and rel_err(gb, b["gb"]) < TOL32
+    ggx, ggb = torch.autograd.grad(gx.square().sum() + gb.square().sum(), [x, bias])
+    assert rel_err(ggx, b["ggx"]) < TOL32_2 and rel_err(ggb, b["ggb"]) < TOL32_2
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(4, 32, 8, 8), (2, 5, 7, 3), (3, 512, 4, 4), (2, 16, 64, 64), (1, 1024, 3, 3)])
+def test_affine_act_all_terms(dev, dtype, shape):
+    import gan_amd.functional as GF
+
+    torch.manual_seed(1)
+    n, c, h, w = shape
+    x = torch.randn(shape).to(dtype)
+    r = torch.randn(shape).to(dtype)
+    noise = torch.randn(n, 1, h, w).to(dtype)
+    a = torch.randn(n, c)
+    b = torch.randn(c)
+    ns = torch.randn(c)
+    tol = TOL32 if dtype == torch.float32 else TOLBF
+
+    def ref(x, a, b, ns, r):
+        v = x.double() * a.double().view(n, c, 1, 1) + b.double().view(1, c, 1, 1) + noise.double() * ns.double().view(1, c, 1, 1) + r.double()
+        return F.leaky_relu(v, 0.2)
+
+    leaves_ref = [t.clone().requires_grad_(True) for t in (x, a, b, ns, r)]
+    leaves = [t.clone().to(dev).requires_grad_(True) for t in (x, a, b, ns, r)]
+    y_ref = ref(*leaves_ref)
+    y = GF.affine_act(leaves[0], leaves[1], leaves[2], noise.to(dev), leaves[3], leaves[4], 0.2)
+    assert rel_err(y, y_ref) < tol
+    cot = torch.randn(shape).to(dtype)
+    g_ref = torch.autograd.grad((y_ref * cot.double()).sum(), leaves_ref)
+    g = torch.autograd.grad((y * cot.to(dev)).sum(), leaves)
+    for name, gr, gg in zip("x a b ns r".split(), g_ref, g):
+        assert rel_err(gg, gr) < 3 * tol, (name, rel_err(gg, gr))
+    # per-channel a (D-block `scale`) and linear slope
+    a_c = torch.randn(c, 1, 1)
+    y2 = GF.affine_act(x.to(dev), a=a_c.to(dev), r=r.to(dev))
+    assert rel_err(y2, x.double() * a_c.double() + r.double()) < tol
+
+
+# ------------------------------------------------------------------------------------------
+CONV_CASES = [
+    # N, Cin, H, W, Cout, k, pad
+    (2, 16, 8, 8, 32, 3, 1),
+    (3, 8, 5, 7, 16, 1, 0),
+    (2, 24, 6, 6, 40, 3, 1),
+    (4, 3, 16, 16, 8, 1, 0),  # from-RGB: Cin padded to 8
+    (4, 33, 4, 4, 32, 3, 1),  # MinibatchStdDev channel: Cin padded
+    (8, 32, 4, 4, 1, 4, 0),  # the 4x4 valid logit conv
+    (2, 16, 4, 4, 3, 1, 0),  # to-RGB
+    (1, 64, 16, 16, 64, 3, 1),
+    (2, 128, 8, 8, 256, 3, 1),
+    (1, 16, 40, 40, 16, 3, 1),
+    (2, 32, 33, 17, 32, 3, 1),  # ragged M
+    (1, 64, 8, 8, 64, 3, 2),  # pad > (k-1)/2
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv2d_fwd_dgrad_wgrad(dev, case, dtype):
+    import gan_amd.functional as GF
+
+    n, cin, h, w, cout, k, pad = case
+    torch.manual_seed(2)
+    x = torch.randn(n, cin, h, w).to(dtype)
+    wgt = torch.randn(cout, cin, k, k) / (cin * k * k) ** 0.5
+    tol = TOL32 if dtype == torch.float32 else TOLBF
+    x_ref = x.double().requires_grad_(True)
+    w_in = wgt.to(dtype).float() if dtype == torch.bfloat16 else wgt  # the kernel rounds W to the compute dtype
+    w_ref = w_in.double().requires_grad_(True)
+    y_ref = F.conv2d(x_ref, w_ref, padding=pad)
+    xg = x.to(dev).requires_grad_(True)
+    wg = wgt.to(dev).requires_grad_(True)
+    y = GF.conv2d(xg, wg, pad)
+    assert y.shape == y_ref.shape and y.dtype == dtype
+    assert rel_err(y, y_ref) < tol, rel_err(y, y_ref)
+    cot = torch.randn(y_ref.shape).to(dtype)
+    gx_ref, gw_ref = torch.autograd.grad((y_ref * cot.double()).sum(), [x_ref, w_ref])
+    gx, gw = torch.autograd.grad((y * cot.to(dev)).sum(), [xg, wg])
+    assert gw.dtype == torch.float32
+    assert rel_err(gx, gx_ref) < tol, ("dgrad", rel_err(gx, gx_ref))
+    assert rel_err(gw, gw_ref) < tol, ("wgrad", rel_err(gw, gw_ref))
+
+
+def test_conv2d_large_tiles(dev):
+    """Shapes that select the 128x128 and 256x16 tile configurations."""
+    import gan_amd.functional as GF
+
+    torch.manual_seed(3)
+    for n, cin, h, w, cout in [(16, 128, 64, 64, 128), (2, 16, 256, 256, 16), (4, 32, 128, 128, 32)]:
+        x = torch.randn(n, cin, h, w)
+        wgt = torch.randn(cout, cin, 3, 3) / (cin * 9) ** 0.5
+        ref = F.conv2d(x, wgt, padding=1)
+        got = GF.conv2d(x.to(dev), wgt.to(dev), 1)
+        assert rel_err(got, ref) < 2e-5
+        got_bf = GF.conv2d(x.to(dev).bfloat16(), wgt.to(dev), 1)
+        assert rel_err(got_bf, ref) < TOLBF
+
+
+def test_conv2d_second_order(dev):
+    """conv is bilinear: check the closed dgrad/wgrad/fwd triangle under create_graph against autograd on the oracle."""
+    import gan_amd.functional as GF
+
+    torch.manual_seed(4)
+    x = torch.randn(2, 16, 6, 6)
+    wgt = torch.randn(24, 16, 3, 3) / 12
+    x_ref = x.double().requires_grad_(True)
+    w_ref = wgt.double().requires_grad_(True)
+    y_ref = F.conv2d(x_ref, w_ref, padding=1)
+    gx_ref, gw_ref = torch.autograd.grad(y_ref.square().sum(), [x_ref, w_ref], create_graph=True)
+    hx_ref, hw_ref = torch.autograd.grad(gx_ref.square().sum() + gw_ref.square().sum(), [x_ref, w_ref])
+    xg = x.to(dev).requires_grad_(True)
+    wg = wgt.to(dev).requires_grad_(True)
+    y = GF.conv2d(xg, wg, 1)
+    gx, gw = torch.autograd.grad(y.square().sum(), [xg, wg], create_graph=True)
+    hx, hw = torch.autograd.grad(gx.square().sum() + gw.square().sum(), [xg, wg])
+    assert rel_err(gx, gx_ref) < TOL32 and rel_err(gw, gw_ref) < TOL32
+    assert rel_err(hx, hx_ref) < TOL32_2 and rel_err(hw, hw_ref) < TOL32_2
+
+
+def test_conv2d_fused_prologue_epilogue(dev):
+    """in_scale / up2 / out_scale / bias / noise / lrelu in the conv kernel against the composed oracle."""
+    import gan_amd.functional as GF
+    from oracle import gan_oracle as O
+
+    torch.manual_seed(5)
+    n, cin, cout, h = 3, 16, 24, 5
+    x = torch.randn(n, cin, h, h)
+    wgt = torch.randn(cout, cin, 3, 3) / 12
+    s = torch.randn(n, cin)
+    d = torch.rand(n, cout) + 0.5
+    b = torch.randn(cout)
+    ns = torch.randn(cout)
+    noise = torch.randn(n, 1, 2 * h, 2 * h)
+    xs = O.nearest_up2(x.double()) * s.double().view(n, cin, 1, 1)
+    ref = F.conv2d(xs, wgt.double(), padding=1) * d.double().view(n, cout, 1, 1) + b.double().view(1, -1, 1, 1)
+    ref = F.leaky_relu(ref + noise.double() * ns.double().view(1, -1, 1, 1), 0.2)
+    for dtype, tol in ((torch.float32, TOL32), (torch.bfloat16, TOLBF)):
+        got = GF.raw_conv2d(
+            x.to(dev).to(dtype), wgt.to(dev), 1, 1, up2=True, in_scale=s.to(dev), out_scale=d.to(dev), bias=b.to(dev),
+            noise=noise.to(dev), noise_scale=ns.to(dev), slope=0.2,
+        )
+        assert rel_err(got, ref) < tol, (dtype, rel_err(got, ref))
+        gy = torch.randn(n, cout, 2 * h, 2 * h)
+        w_ref = wgt.double().requires_grad_(True)
+        (gw_ref,) = torch.autograd.grad((F.conv2d(xs, w_ref, padding=1) * gy.double()).sum(), w_ref)
+        gw = GF.raw_conv2d_wgrad(x.to(dev).to(dtype), gy.to(dev).to(dtype), 3, 3, 1, 1, up2=True, in_scale=s.to(dev))
+        assert rel_err(gw, gw_ref) < tol, (dtype, "wgrad", rel_err(gw, gw_ref))
+
+
+def test_ema_lerp_and_mbstd_kernels(dev, golden):
+    import gan_amd.functional as GF
+    from oracle import gan_oracle as O
+
+    torch.manual_seed(6)
+    for n in (1, 7, 4096, 100003):
+        e = torch.randn(n, device=dev)
+        p = torch.randn(n, device=dev)
+        ref = e.clone().lerp_(p, 0.001)
+        GF.raw_ema_lerp(e, p, 0.001)
+        assert rel_err(e, ref) < 1e-6
+    m = golden("small_ops")["mbstd"]
+    stat = GF.raw_mbstd_stat(m["x"].to(dev), 4)
+    assert rel_err(stat, m["y"][:2, -1, 0, 0]) < TOL32
+    x = torch.randn(16, 512, 4, 4)
+    ref = O.minibatch_stddev(x.double())[:4, -1, 0, 0]
+    assert rel_err(GF.raw_mbstd_stat(x.to(dev), 4), ref) < TOL32
+    assert rel_err(GF.raw_mbstd_stat(x.to(dev).bfloat16(), 4), ref) < TOLBF
