@@ -1,0 +1,195 @@
+"""The train_celeba.py step on the HIP kernels (reference: train_celeba.py:23-49 config, :60-77 set-up,
+:111-149 loop body), with synthetic CelebA-shaped data and optional batch data parallelism.
+
+    python -m gan_amd.train_celeba --model stylegan2 --img_size 64 --gen_kwargs '{"base_dim":64}' \
+        --disc_kwargs '{"base_dim":64}' --method hinge --regularizer r1 --mixed_precision --channels_last \
+        --optimizer Adam --optimizer_kwargs '{"betas":[0.0,0.9]}' --batch_size 64 --n_iters 100
+    torchrun --nproc-per-node 8 -m gan_amd.train_celeba ... --batch_size 256     # global batch, sharded
+
+Out of scope here: the CelebA loader, wandb, PNG dumps, FID, DiffAugment.
+"""
+import json
+import time
+from dataclasses import dataclass, field
+from typing import Callable, Dict, Iterator, List, Optional
+
+import torch
+from torch import Tensor, nn
+
+from .distributed import GradBucketReducer, init_from_env, interleaved_shard
+from .losses import get_loss, get_regularizer
+from .modelling import build_discriminator, build_generator
+from .utils import EMA, make_parser, prepare_model
+
+
+@dataclass
+class TrainConfig:
+    model: str = "dcgan"
+    img_size: int = 64
+    disc_kwargs: dict = field(default_factory=dict)
+    gen_kwargs: dict = field(default_factory=dict)
+    sn_disc: bool = False
+    sn_gen: bool = False
+
+    device: str = "cuda" if torch.cuda.is_available() else "cpu"
+    mixed_precision: bool = False
+    channels_last: bool = False
+    compile: bool = False
+    grad_accum: int = 1
+    n_iters: int = 30_000
+    n_disc: int = 1
+    lr: float = 2e-4
+    optimizer: str = "Adam"
+    optimizer_kwargs: dict = field(default_factory=dict)
+    batch_size: int = 64
+    method: str = "gan"
+    regularizer: str = "none"
+    diff_augment: bool = False
+
+    run_name: str = "dcgan_celeba"
+    log_img_interval: int = 1_000
+    fid_interval: int = 5_000
+
+
+def _fix_betas(kwargs: dict) -> dict:
+    """README.md:60 passes betas [0, 0.9]; recent torch.optim.Adam rejects the int 0."""
+    kwargs = dict(kwargs)
+    if "betas" in kwargs:
+        kwargs["betas"] = tuple(float(b) for b in kwargs["betas"])
+    return kwargs
+
+
+class Trainer:
+    """State of the loop in train_celeba.py:60-77 plus the data-parallel reducers."""
+
+    def __init__(self, cfg: TrainConfig, device: Optional[torch.device] = None, world: int = 1, z_dim: int = 128):
+        if cfg.diff_augment:
+            raise NotImplementedError("DiffAugment is outside the hot path (SURVEY.md section 2 row 11)")
+        self.cfg = cfg
+        self.device = torch.device(device if device is not None else cfg.device)
+        self.world = world
+        self.z_dim = z_dim
+        self.disc = build_discriminator(cfg.model, img_size=cfg.img_size, **cfg.disc_kwargs).to(self.device)
+        self.gen = build_generator(cfg.model, img_size=cfg.img_size, **cfg.gen_kwargs).to(self.device)
+        prepare_model(self.disc, spectral_norm=cfg.sn_disc, channels_last=cfg.channels_last, compile=cfg.compile)
+        prepare_model(self.gen, spectral_norm=cfg.sn_gen, channels_last=cfg.channels_last, compile=cfg.compile)
+        if world > 1:
+            self._broadcast_parameters()
+        # gradient arenas + bucketed all-reduce (single process: the hooks are inert, arenas still used)
+        self.red_d = GradBucketReducer(self.disc)
+        self.red_g = GradBucketReducer(self.gen)
+        self.gen_ema = EMA(self.gen)
+        self.criterion = get_loss(cfg.method)
+        self.regularizer = get_regularizer(cfg.regularizer)
+        optim_cls = getattr(torch.optim, cfg.optimizer)
+        okw = _fix_betas(cfg.optimizer_kwargs)
+        self.optim_d = optim_cls(self.disc.parameters(), cfg.lr, **okw)
+        self.optim_g = optim_cls(self.gen.parameters(), cfg.lr, **okw)
+        self.autocast_ctx = lambda: torch.autocast(self.device.type, dtype=torch.bfloat16, enabled=cfg.mixed_precision)
+        self.step = 0
+
+    def _broadcast_parameters(self) -> None:
+        import torch.distributed as dist
+
+        for m in (self.disc, self.gen):
+            for t in list(m.parameters()) + list(m.buffers()):
+                dist.broadcast(t.data, src=0)
+
+    def train_step(self, next_reals: Callable[[], Tensor]) -> Dict[str, Tensor]:
+        """One generator iteration = the `while` body of train_celeba.py:111-149.  `next_reals()` returns
+        this rank's (local_batch // grad_accum, 3, S, S) real images, already on the device."""
+        cfg, disc, gen = self.cfg, self.disc, self.gen
+        for i in range(cfg.n_disc):
+            cached_reals: Optional[List[Tensor]] = [] if i == cfg.n_disc - 1 else None
+            if cfg.method == "wgan" and cfg.regularizer == "none":
+                with torch.no_grad():
+                    for p in disc.parameters():
+                        p.clip_(-0.01, 0.01)
+            for a in range(cfg.grad_accum):
+                reals = next_reals()
+                if cached_reals is not None:
+                    cached_reals.append(reals.clone())
+                reals.requires_grad_()
+                zs = torch.randn(reals.shape[0], self.z_dim, device=self.device)
+                with self.autocast_ctx():
+                    with torch.no_grad():
+                        fakes = gen(zs)
+                    d_reals = disc(reals)
+                    d_fakes = disc(fakes)
+                    loss_d = self.criterion.d_loss(d_reals, d_fakes)
+                    if self.regularizer is not None:
+                        loss_d = loss_d + self.regularizer(disc, reals, fakes, d_reals)
+                last = a == cfg.grad_accum - 1
+                if last:
+                    self.red_d.prepare()
+                loss_d.backward()
+                if last:
+                    self.red_d.finish()
+            self.optim_d.step()
+            self.red_d.zero_grad()
+
+        disc.requires_grad_(False)
+        for a in range(cfg.grad_accum):
+            zs = torch.randn(reals.shape[0], self.z_dim, device=self.device)
+            with self.autocast_ctx():
+                loss_g = self.criterion.g_loss(disc(gen(zs)), lambda: disc(cached_reals[a]))
+            last = a == cfg.grad_accum - 1
+            if last:
+                self.red_g.prepare()
+            loss_g.backward()
+            if last:
+                self.red_g.finish()
+        self.optim_g.step()
+        self.red_g.zero_grad()
+        disc.requires_grad_(True)
+        self.gen_ema.step()
+        self.step += 1
+        # tensors, not floats: no host sync here (the reference syncs every 50 steps, train_celeba.py:153-160)
+        return {"loss/d": loss_d.detach(), "d/real": d_reals.detach().mean(), "d/fake": d_fakes.detach().mean(), "loss/g": loss_g.detach()}
+
+
+def synthetic_reals(cfg: TrainConfig, device: torch.device, local_batch: int, seed: int = 0) -> Callable[[], Tensor]:
+    """CelebA-shaped stand-in: N(0,1) images (the real pipeline normalises to about [-1, 1],
+    train_celeba.py:79-87), a small device-resident pool cycled so no host work sits in the step."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    pool = [torch.randn(local_batch, 3, cfg.img_size, cfg.img_size, generator=g).to(device) for _ in range(4)]
+    if cfg.channels_last:
+        pool = [p.contiguous(memory_format=torch.channels_last) for p in pool]
+    state = {"i": 0}
+
+    def next_reals() -> Tensor:
+        state["i"] += 1
+        return pool[state["i"] % len(pool)].clone()
+
+    return next_reals
+
+
+def main(argv=None) -> None:
+    args = make_parser(TrainConfig).parse_args(argv)
+    cfg = TrainConfig(**vars(args))
+    rank, world, device = init_from_env(cfg.device)
+    if rank == 0:
+        print("Config:")
+        for k, v in vars(cfg).items():
+            print(f"  {k}: {v}")
+    if cfg.batch_size % (world * cfg.grad_accum) != 0:
+        raise ValueError("batch_size must divide evenly over ranks and grad_accum")
+    local_batch = cfg.batch_size // world // cfg.grad_accum
+    torch.manual_seed(1234 + rank)
+    trainer = Trainer(cfg, device, world)
+    next_reals = synthetic_reals(cfg, device, local_batch, seed=rank)
+    t0 = time.perf_counter()
+    while trainer.step < cfg.n_iters:
+        logs = trainer.train_step(next_reals)
+        if trainer.step % 50 == 0 and rank == 0:
+            if device.type == "cuda":
+                torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            rec = {k: float(v) for k, v in logs.items()}
+            rec.update(step=trainer.step, img_per_s=50 * cfg.batch_size / dt)
+            print(json.dumps(rec), flush=True)
+            t0 = time.perf_counter()
+
+
+if __name__ == "__main__":
+    main()
