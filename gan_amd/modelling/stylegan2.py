@@ -99,23 +99,39 @@ class ModConvFn(Function):
 
     @staticmethod
     def _backward_differentiable(ctx, gy):
+        """The same gradients as `backward`, written as a composition of gan_amd.functional's
+        differentiable primitives applied to the saved tensors and gy, so autograd records a graph of
+        HIP-kernel Functions it can differentiate again (each primitive is local: no gradient flows
+        through the history of s / dinv here, the outer graph does that)."""
         x, weight, s, dinv, bias, noise, ns, y = ctx.saved_tensors
         slope, up2, pad = ctx.slope, ctx.up2, ctx.pad
-        with torch.enable_grad():
-            xu = GF.nearest_up2(x) if up2 else x
-            xs = GF.ChanScaleFn.apply(xu, s)
-            z = GF.Conv2dFn.apply(xs, weight, pad, pad)
-            y2 = GF.AffineActFn.apply(z, dinv, bias, noise, ns, None, slope)
-            inputs, slots = [], []
-            for i, t in enumerate((x, weight, s, dinv, bias, None, ns)):
-                if t is not None and ctx.needs_input_grad[i]:
-                    inputs.append(t)
-                    slots.append(i)
-            grads = torch.autograd.grad(y2, inputs, gy, create_graph=True, allow_unused=True)
-        out = [None] * 9
-        for i, g in zip(slots, grads):
-            out[i] = g
-        return tuple(out)
+        need = ctx.needs_input_grad
+        kh, kw = weight.shape[2], weight.shape[3]
+        gp = GF.MaskMulFn.apply(gy, y, slope) if slope != 1.0 else gy  # gradient at the pre-activation
+        xu = GF.nearest_up2(x) if up2 else x
+        xs = GF.ChanScaleFn.apply(xu, s)
+        gx = gw = gs = gdinv = gb = gns = None
+        if bias is not None and need[4]:
+            gb = GF.ChanSumFn.apply(gp, False).reshape(bias.shape).to(bias.dtype)
+        if ns is not None and need[6]:
+            gns = GF.PixelDotFn.apply(gp, noise).reshape(ns.shape).to(ns.dtype)
+        gz = gp
+        if dinv is not None:
+            if need[3]:
+                z = GF.Conv2dFn.apply(xs, weight, pad, pad)  # recomputed: the forward kernel stores only y
+                gdinv = GF.ChanDotFn.apply(gp, z, True).reshape(dinv.shape).to(dinv.dtype)
+            gz = GF.ChanScaleFn.apply(gp, dinv)
+        if need[0] or need[2]:
+            gxs = GF.Conv2dDgradFn.apply(gz, weight, pad, pad)
+            if need[2]:
+                gs = GF.ChanDotFn.apply(gxs, xu, True).reshape(s.shape).to(s.dtype)
+            if need[0]:
+                gx = GF.ChanScaleFn.apply(gxs, s)
+                if up2:  # adjoint of nearest x2: sum of each 2x2 block
+                    gx = GF.UpFirDnFn.apply(gx, torch.ones(2, 2, device=gx.device), 1, 2, 0, 0, 0, 0)
+        if need[1]:
+            gw = GF.Conv2dWgradFn.apply(xs, gz, kh, kw, pad, pad).to(weight.dtype)
+        return gx, gw, gs, gdinv, gb, None, gns, None, None
 
 
 class ModulatedConv2d(nn.Conv2d):
