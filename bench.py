@@ -1,0 +1,267 @@
+"""Benchmark of the StyleGAN2 hinge + R1 training step on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[3], the configuration the metric is quoted on): StyleGAN2 generator +
+discriminator (base_dim 16 both, 10.2 M / 9.9 M parameters), 256x256, GLOBAL batch 256 split evenly over
+the ranks (strong scaling), hinge loss + R1 every step, Adam(2e-4, betas (0, 0.9)), bf16 autocast +
+channels_last, EMA; synthetic CelebA-shaped reals resident in HBM.  A "step" is one generator iteration
+of train_celeba.py:111-149: one D update (with the R1 double backward) + one G update + EMA.
+
+Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  roofline      -- the kernel family with the largest share of device time in one extra, event-bracketed
+                   step after the timed region (HIP events on the launch stream around every C-ABI call)
+  cpu_baseline  -- the oracle (CPU restatement of the reference, fp32) timed on the host cores on a
+                   bounded sample of the same workload (rank 0, N=1 only)
+  upfirdn2d     -- config[1] microbenchmark: achieved HBM GB/s of the upfirdn2d / bias+leaky-ReLU kernels
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--img_size", type=int, default=256)
+    ap.add_argument("--global_batch", type=int, default=256)
+    ap.add_argument("--micro_batch", type=int, default=256, help="largest per-rank batch per backward pass (grad_accum above it)")
+    ap.add_argument("--base_dim", type=int, default=16)
+    ap.add_argument("--fp32", action="store_true", help="fp32 instead of bf16 autocast (debug)")
+    ap.add_argument("--no_cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no_micro", action="store_true", help="skip the upfirdn2d microbenchmark leg")
+    ap.add_argument("--no_roofline", action="store_true")
+    return ap.parse_args()
+
+
+def make_trainer(args, device, world):
+    from gan_amd.train_celeba import TrainConfig, Trainer
+
+    local = args.global_batch // world
+    # grad_accum (train_celeba.py:38,120): smallest split whose micro-batch fits --micro_batch and keeps
+    # whole MinibatchStdDev groups of 4
+    accum = next(a for a in range(1, local + 1) if local % a == 0 and local // a <= args.micro_batch and (local // a) % 4 == 0)
+    cfg = TrainConfig(
+        model="stylegan2", img_size=args.img_size, gen_kwargs={"base_dim": args.base_dim}, disc_kwargs={"base_dim": args.base_dim},
+        method="hinge", regularizer="r1", batch_size=args.global_batch, optimizer="Adam", optimizer_kwargs={"betas": [0.0, 0.9]},
+        lr=2e-4, device="cuda", mixed_precision=not args.fp32, channels_last=True, grad_accum=accum,
+    )
+    return cfg, Trainer(cfg, device, world), local // accum
+
+
+def roofline_leg(trainer, next_reals):
+    """One extra step with every C-ABI launch bracketed by events; returns the roofline object of the
+    dominant family and the per-family table."""
+    import gan_amd.functional as GF
+
+    prof = GF.KernelProfile()
+    GF.set_profile(prof)
+    try:
+        trainer.train_step(next_reals)
+        torch.cuda.synchronize()
+    finally:
+        GF.set_profile(None)
+    table = prof.summary()
+    total_ms = sum(d["ms"] for d in table.values())
+    fams = {}
+    for name, d in table.items():
+        sec = d["ms"] * 1e-3
+        fams[name] = dict(
+            launches=d["launches"], ms=round(d["ms"], 3), share=round(d["ms"] / total_ms, 4),
+            tflops=round(d["flops"] / sec / 1e12, 2) if d["flops"] else None,
+            gbs=round(d["bytes"] / sec / 1e9, 1),
+        )
+    dom = max(table, key=lambda k: table[k]["ms"])
+    d = table[dom]
+    sec = d["ms"] * 1e-3
+    if d["flops"]:
+        ach = d["flops"] / sec / 1e12
+        roof = dict(kernel=dom, bound="mfma", achieved=round(ach, 2), peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s",
+                    frac=round(ach / MFMA_BF16_PEAK_TFLOPS, 4), traffic=None,
+                    launches=d["launches"], avg_launch_us=round(d["ms"] * 1e3 / d["launches"], 2),
+                    hbm_gbs=round(d["bytes"] / sec / 1e9, 1))
+    else:
+        ach = d["bytes"] / sec / 1e9
+        roof = dict(kernel=dom, bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=round(ach / HBM_PEAK_GBS, 4), traffic=None,
+                    launches=d["launches"], avg_launch_us=round(d["ms"] * 1e3 / d["launches"], 2))
+    return roof, fams
+
+
+def micro_leg(device):
+    """BASELINE config[1]: benchmark_upfirdn2d.py shapes, bf16 channels_last, 3x3 FIR, up = down = 1, pad 1;
+    plus 2x up / 2x down with the 4-tap binomial FIR and the fused bias + leaky-ReLU.  Algorithmic bytes =
+    (numel_in + numel_out) * 2 per call."""
+    import gan_amd.functional as GF
+    from gan_amd.modelling.nvidia_ops import Blur
+
+    shapes = [(32, 512, 4, 4), (32, 512, 8, 8), (32, 512, 16, 16), (32, 512, 32, 32), (32, 256, 64, 64),
+              (32, 128, 128, 128), (32, 64, 256, 256), (32, 32, 512, 512), (32, 16, 1024, 1024)]
+    k3 = torch.randn(3, 3, device=device)
+    k4 = Blur.make_kernel(4).to(device)
+    out = {}
+
+    def timeit(fn, iters):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e-3 / iters
+
+    for shp in shapes:
+        x = torch.randn(shp, device=device, dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        n, c, h, w = shp
+        numel = x.numel()
+        iters = 100 if numel < (1 << 26) else 20
+        key = "x".join(map(str, shp))
+        rec = {}
+        t = timeit(lambda: GF.raw_upfirdn2d(x, k3, 1, 1, 1, 1, h, w), iters)
+        rec["fir3_gbs"] = round(4 * numel / t / 1e9, 1)
+        t = timeit(lambda: GF.raw_affine_act(x, b=torch.zeros(c, device=device), slope=0.2), iters)
+        rec["bias_lrelu_gbs"] = round(4 * numel / t / 1e9, 1)
+        if numel <= (1 << 27):
+            t = timeit(lambda: GF.raw_upfirdn2d(x, k4, 2, 1, 2, 2, 2 * h, 2 * w), iters)
+            rec["up2_fir4_gbs"] = round(2 * 5 * numel / t / 1e9, 1)
+        t = timeit(lambda: GF.raw_upfirdn2d(x, k4, 1, 2, 1, 1, h // 2, w // 2), iters)
+        rec["down2_fir4_gbs"] = round(2 * 1.25 * numel / t / 1e9, 1)
+        out[key] = rec
+        del x
+    big = out["32x16x1024x1024"]
+    return dict(shapes=out, peak_gbs=HBM_PEAK_GBS, fir3_frac_at_largest=round(big["fir3_gbs"] / HBM_PEAK_GBS, 4),
+                bias_lrelu_frac_at_largest=round(big["bias_lrelu_gbs"] / HBM_PEAK_GBS, 4))
+
+
+def cpu_leg(args):
+    """The oracle's train_iteration (fp32, reference init) on the host cores: same model and image size,
+    batch 4, one warm-up + timed iterations bounded to about 20 s."""
+    from oracle import gan_oracle as O
+
+    torch.manual_seed(0)
+    batch = 4
+    g_sd, d_sd = O.new_stylegan2_state(args.img_size, args.base_dim, args.base_dim)
+    opt_d = torch.optim.Adam(list(d_sd.values()), 2e-4, betas=(0.0, 0.9))
+    opt_g = torch.optim.Adam(list(g_sd.values()), 2e-4, betas=(0.0, 0.9))
+    reals = torch.randn(batch, 3, args.img_size, args.img_size)
+    threads = min(16, os.cpu_count() or 1)  # the box's CPU share for one GPU
+    torch.set_num_threads(threads)
+    O.train_iteration(g_sd, d_sd, opt_g, opt_d, lambda: reals.clone(), method="hinge", reg="r1")  # warm-up
+    t0 = time.perf_counter()
+    iters = 0
+    while iters < 10 and (iters == 0 or time.perf_counter() - t0 < 20.0):
+        O.train_iteration(g_sd, d_sd, opt_g, opt_d, lambda: reals.clone(), method="hinge", reg="r1")
+        iters += 1
+    dt = (time.perf_counter() - t0) / iters
+    return dict(value=round(batch / dt, 3), unit="img/s", cores=threads, kind="port",
+                sample=f"oracle (fp32 PyTorch restatement of the reference) hinge+R1 step, {args.img_size}x{args.img_size}, batch {batch}, {iters} timed iteration(s) after 1 warm-up")
+
+
+def main():
+    args = parse()
+    from gan_amd.distributed import init_from_env
+    from gan_amd.train_celeba import synthetic_reals
+
+    rank, world, device = init_from_env("cuda")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE is {world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if args.global_batch % (4 * world) != 0:
+        raise SystemExit("global batch must be a multiple of 4 * gpus (MinibatchStdDev groups)")
+    torch.manual_seed(1234 + rank)
+    cfg, trainer, micro = make_trainer(args, device, world)
+    next_reals = synthetic_reals(cfg, device, micro, seed=rank)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        trainer.train_step(next_reals)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        trainer.train_step(next_reals)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    logs = trainer.train_step(next_reals)  # sanity: losses stay finite
+    finite = all(bool(torch.isfinite(v).all()) for v in logs.values())
+    peak_mem = torch.cuda.max_memory_allocated(device) / 2**30
+
+    roof = fams = micro_res = cpu = None
+    if rank == 0:
+        if not args.no_roofline:
+            roof, fams = roofline_leg(trainer, next_reals)
+    if world > 1:
+        dist.barrier()
+    if rank == 0 and world == 1:
+        del trainer
+        torch.cuda.empty_cache()
+        if not args.no_micro:
+            micro_res = micro_leg(device)
+        if not args.no_cpu:
+            cpu = cpu_leg(args)
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        line = {
+            "metric": "StyleGAN2 G+D+R1 train img/s @256x256" if args.img_size == 256 else f"StyleGAN2 G+D+R1 train img/s @{args.img_size}",
+            "value": round(args.global_batch * args.steps / elapsed, 2),
+            "unit": "img/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms, 2),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "fp32" if args.fp32 else "bf16",
+            "data": "synthetic",
+            "config": {
+                "workload": f"StyleGAN2 hinge+R1 train step, {args.img_size}x{args.img_size}, base_dim {args.base_dim}, global batch {args.global_batch}, Adam, EMA",
+                "global_batch": args.global_batch,
+                "per_gpu_batch": args.global_batch // world,
+                "grad_accum": cfg.grad_accum,
+                "parallelism": f"dp{world}",
+                "losses_finite": finite,
+                "peak_mem_gib": round(peak_mem, 1),
+            },
+            "roofline": roof,
+            "kernels": fams,
+            "cpu_baseline": cpu,
+            "upfirdn2d": micro_res,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

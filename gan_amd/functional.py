@@ -33,6 +33,56 @@ CL = torch.channels_last
 
 
 # ======================================================================================
+# optional per-launch measurement (bench.py's roofline leg): HIP events on the launch stream
+# ======================================================================================
+class KernelProfile:
+    """Brackets every C-ABI launch with two events on the stream the kernel is enqueued on and keeps its
+    algorithmic work (flops for the MFMA kernels, HBM bytes for the streaming kernels).  Off by default:
+    the training path pays one `is None` test per launch."""
+
+    def __init__(self):
+        self.records = []  # (family, flops, bytes, start_event, end_event)
+
+    def launch(self, family: str, flops: float, nbytes: float, thunk):
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = thunk()
+        e1.record()
+        self.records.append((family, float(flops), float(nbytes), e0, e1))
+        return out
+
+    def summary(self):
+        """family -> dict(launches, ms, flops, bytes); call after torch.cuda.synchronize()."""
+        out = {}
+        for family, flops, nbytes, e0, e1 in self.records:
+            d = out.setdefault(family, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
+            d["launches"] += 1
+            d["ms"] += e0.elapsed_time(e1)
+            d["flops"] += flops
+            d["bytes"] += nbytes
+        return out
+
+
+_PROFILE: Optional[KernelProfile] = None
+
+
+def set_profile(profile: Optional[KernelProfile]) -> None:
+    global _PROFILE
+    _PROFILE = profile
+
+
+def _run(family: str, flops: float, nbytes: float, thunk):
+    if _PROFILE is None:
+        return thunk()
+    return _PROFILE.launch(family, flops, nbytes, thunk)
+
+
+def _nbytes(*tensors) -> int:
+    return sum(t.numel() * t.element_size() for t in tensors if t is not None)
+
+
+# ======================================================================================
 # raw (non-differentiable) kernel launchers
 # ======================================================================================
 def as_cl(x: Tensor) -> Tensor:
@@ -64,7 +114,10 @@ def raw_upfirdn2d(x: Tensor, taps: Tensor, up: int, down: int, px1: int, py1: in
     ky, kx = taps32.shape
     y = _empty_like_cl(x, (n, c, ho, wo))
     check(
-        lib.gan_upfirdn2d(ptr(x), ptr(taps32), ptr(y), n, h, w, c, ky, kx, up, down, px1, py1, ho, wo, dtype_code(x), stream_of(x)),
+        _run(
+            "upfirdn2d", 0, _nbytes(x, y),
+            lambda: lib.gan_upfirdn2d(ptr(x), ptr(taps32), ptr(y), n, h, w, c, ky, kx, up, down, px1, py1, ho, wo, dtype_code(x), stream_of(x)),
+        ),
         "gan_upfirdn2d",
     )
     return y
@@ -105,8 +158,11 @@ def raw_affine_act(
         assert r.shape == x.shape
     y = _empty_like_cl(x, x.shape)
     check(
-        lib.gan_affine_act_fwd(
-            ptr(x), ptr(a32), a_sn, ptr(b32), ptr(noise), ptr(ns32), ptr(r), ptr(y), n, h * w, c, float(slope), dtype_code(x), stream_of(x)
+        _run(
+            "affine_act", 0, _nbytes(x, y, r, noise),
+            lambda: lib.gan_affine_act_fwd(
+                ptr(x), ptr(a32), a_sn, ptr(b32), ptr(noise), ptr(ns32), ptr(r), ptr(y), n, h * w, c, float(slope), dtype_code(x), stream_of(x)
+            ),
         ),
         "gan_affine_act_fwd",
     )
@@ -124,7 +180,10 @@ def raw_mask_scale(g: Tensor, ymask: Optional[Tensor], a: Optional[Tensor], slop
     a32, a_sn = _side(a, n, c, "mask_scale a")
     out = _empty_like_cl(g, g.shape)
     check(
-        lib.gan_mask_scale(ptr(g), ptr(ymask), ptr(a32), a_sn, ptr(out), n, h * w, c, float(slope), dtype_code(g), stream_of(g)),
+        _run(
+            "mask_scale", 0, _nbytes(g, ymask, out),
+            lambda: lib.gan_mask_scale(ptr(g), ptr(ymask), ptr(a32), a_sn, ptr(out), n, h * w, c, float(slope), dtype_code(g), stream_of(g)),
+        ),
         "gan_mask_scale",
     )
     return out
@@ -147,7 +206,10 @@ def raw_chan_dot(A: Tensor, B: Optional[Tensor], b_mode: int, ymask: Optional[Te
         ymask = as_cl(ymask.detach().to(A.dtype))
     out = torch.empty((n, c) if per_sample else (c,), dtype=torch.float32, device=A.device)
     check(
-        lib.gan_chan_dot(ptr(A), ptr(B), b_mode, ptr(ymask), float(slope), ptr(out), c if per_sample else 0, n, h * w, c, dtype_code(A), stream_of(A)),
+        _run(
+            "chan_dot", 0, _nbytes(A, B, ymask),
+            lambda: lib.gan_chan_dot(ptr(A), ptr(B), b_mode, ptr(ymask), float(slope), ptr(out), c if per_sample else 0, n, h * w, c, dtype_code(A), stream_of(A)),
+        ),
         "gan_chan_dot",
     )
     return out
@@ -216,9 +278,12 @@ def raw_conv2d(
         noise = noise.detach().to(x.dtype).reshape(n, ho * wo).contiguous()
     y = _empty_like_cl(x, (n, cout, ho, wo))
     check(
-        lib.gan_conv2d_fwd(
-            ptr(x), ptr(wt), ptr(y), ptr(in_scale), ptr(out_scale32), ptr(bias32), ptr(noise), ptr(ns32), float(slope),
-            n, h, w, cin_p, int(up2), ho, wo, cout, kh, kw, py, px, kpad, dtype_code(x), stream_of(x),
+        _run(
+            "conv2d_fwd", 2.0 * n * ho * wo * cout * cin * kh * kw, _nbytes(x, y, wt, noise),
+            lambda: lib.gan_conv2d_fwd(
+                ptr(x), ptr(wt), ptr(y), ptr(in_scale), ptr(out_scale32), ptr(bias32), ptr(noise), ptr(ns32), float(slope),
+                n, h, w, cin_p, int(up2), ho, wo, cout, kh, kw, py, px, kpad, dtype_code(x), stream_of(x),
+            ),
         ),
         "gan_conv2d_fwd",
     )
@@ -251,8 +316,11 @@ def raw_conv2d_wgrad(
             in_scale = F.pad(in_scale, (0, cin_p - cin)).contiguous()
     dw = torch.empty((kh * kw, cout_p, cin_p), dtype=torch.float32, device=x.device)
     check(
-        lib.gan_conv2d_wgrad(
-            ptr(x), ptr(gy), ptr(dw), ptr(in_scale), n, h, w, cin_p, int(up2), ho, wo, cout_p, kh, kw, py, px, dtype_code(x), stream_of(x)
+        _run(
+            "conv2d_wgrad", 2.0 * n * ho * wo * cout * cin * kh * kw, _nbytes(x, gy, dw),
+            lambda: lib.gan_conv2d_wgrad(
+                ptr(x), ptr(gy), ptr(dw), ptr(in_scale), n, h, w, cin_p, int(up2), ho, wo, cout_p, kh, kw, py, px, dtype_code(x), stream_of(x)
+            ),
         ),
         "gan_conv2d_wgrad",
     )
