@@ -92,4 +92,10 @@ __device__ __forceinline__ void store_f<bf16, 1>(bf16* p, const float (&in)[1]) 
 __device__ __forceinline__ float lrelu_f(float v, float slope) { return v > 0.f ? v : v * slope; }
 __device__ __forceinline__ float lrelu_mask(float y, float slope) { return y > 0.f ? 1.f : slope; }
 
+// conv_thin.hip: direct convolution for thin layers (bf16).  1 = served, 0 = shape not eligible, < 0 = error.
+int gan_conv2d_fwd_thin(const void* x, const void* wt, void* y, const float* in_scale, const float* out_scale,
+                        const float* bias, const void* noise, const float* noise_scale, float slope, int N, int H,
+                        int W, int Cin, int up2, int Ho, int Wo, int Cout, int kh, int kw, int py, int px, int Kpad,
+                        hipStream_t st);
+
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -342,5 +342,9 @@ extern "C" int gan_conv2d_fwd(const void* x, const void* wt, void* y, const floa
     a.M = (int64_t)N * Ho * Wo;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == GAN_F32) return launch<float>(a, st);
+    // thin layers (Cin, Cout <= 64 at >= 32 pixels wide) are HBM-bound: halo-tiled direct kernel
+    const int thin = gan_conv2d_fwd_thin(x, wt, y, in_scale, out_scale, bias, noise, noise_scale, slope, N, H, W, Cin,
+                                         up2, Ho, Wo, Cout, kh, kw, py, px, Kpad, st);
+    if (thin != 0) return thin < 0 ? thin : GAN_OK;
     return launch<bf16>(a, st);
 }

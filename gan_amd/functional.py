@@ -43,19 +43,30 @@ class KernelProfile:
     def __init__(self):
         self.records = []  # (family, flops, bytes, start_event, end_event)
 
-    def launch(self, family: str, flops: float, nbytes: float, thunk):
+    def launch(self, family: str, flops: float, nbytes: float, thunk, tag=None):
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
         out = thunk()
         e1.record()
-        self.records.append((family, float(flops), float(nbytes), e0, e1))
+        self.records.append((family, float(flops), float(nbytes), e0, e1, tag))
+        return out
+
+    def by_shape(self):
+        """(family, tag) -> dict(launches, ms, flops, bytes), for the per-layer table of DESIGN.md."""
+        out = {}
+        for family, flops, nbytes, e0, e1, tag in self.records:
+            d = out.setdefault((family, tag), dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
+            d["launches"] += 1
+            d["ms"] += e0.elapsed_time(e1)
+            d["flops"] += flops
+            d["bytes"] += nbytes
         return out
 
     def summary(self):
         """family -> dict(launches, ms, flops, bytes); call after torch.cuda.synchronize()."""
         out = {}
-        for family, flops, nbytes, e0, e1 in self.records:
+        for family, flops, nbytes, e0, e1, _tag in self.records:
             d = out.setdefault(family, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
             d["launches"] += 1
             d["ms"] += e0.elapsed_time(e1)
@@ -72,10 +83,10 @@ def set_profile(profile: Optional[KernelProfile]) -> None:
     _PROFILE = profile
 
 
-def _run(family: str, flops: float, nbytes: float, thunk):
+def _run(family: str, flops: float, nbytes: float, thunk, tag=None):
     if _PROFILE is None:
         return thunk()
-    return _PROFILE.launch(family, flops, nbytes, thunk)
+    return _PROFILE.launch(family, flops, nbytes, thunk, tag)
 
 
 def _nbytes(*tensors) -> int:
@@ -117,6 +128,7 @@ def raw_upfirdn2d(x: Tensor, taps: Tensor, up: int, down: int, px1: int, py1: in
         _run(
             "upfirdn2d", 0, _nbytes(x, y),
             lambda: lib.gan_upfirdn2d(ptr(x), ptr(taps32), ptr(y), n, h, w, c, ky, kx, up, down, px1, py1, ho, wo, dtype_code(x), stream_of(x)),
+            (n, c, h, w, ky, up, down),
         ),
         "gan_upfirdn2d",
     )
@@ -163,6 +175,7 @@ def raw_affine_act(
             lambda: lib.gan_affine_act_fwd(
                 ptr(x), ptr(a32), a_sn, ptr(b32), ptr(noise), ptr(ns32), ptr(r), ptr(y), n, h * w, c, float(slope), dtype_code(x), stream_of(x)
             ),
+            (n, c, h, w),
         ),
         "gan_affine_act_fwd",
     )
@@ -183,6 +196,7 @@ def raw_mask_scale(g: Tensor, ymask: Optional[Tensor], a: Optional[Tensor], slop
         _run(
             "mask_scale", 0, _nbytes(g, ymask, out),
             lambda: lib.gan_mask_scale(ptr(g), ptr(ymask), ptr(a32), a_sn, ptr(out), n, h * w, c, float(slope), dtype_code(g), stream_of(g)),
+            (n, c, h, w),
         ),
         "gan_mask_scale",
     )
@@ -204,15 +218,19 @@ def raw_chan_dot(A: Tensor, B: Optional[Tensor], b_mode: int, ymask: Optional[Te
         B = None
     if ymask is not None:
         ymask = as_cl(ymask.detach().to(A.dtype))
-    out = torch.empty((n, c) if per_sample else (c,), dtype=torch.float32, device=A.device)
+    # Always reduce per sample in the kernel: N x fewer workgroups add into one address (a batch-wide sum
+    # straight from the kernel is bound by fp32-atomic contention, 0.08-0.17 TB/s measured); the (N, C)
+    # partials are folded over N by one tiny reduction.
+    out = torch.empty((n, c), dtype=torch.float32, device=A.device)
     check(
         _run(
             "chan_dot", 0, _nbytes(A, B, ymask),
-            lambda: lib.gan_chan_dot(ptr(A), ptr(B), b_mode, ptr(ymask), float(slope), ptr(out), c if per_sample else 0, n, h * w, c, dtype_code(A), stream_of(A)),
+            lambda: lib.gan_chan_dot(ptr(A), ptr(B), b_mode, ptr(ymask), float(slope), ptr(out), c, n, h * w, c, dtype_code(A), stream_of(A)),
+            (n, c, h, w, b_mode, int(ymask is not None), int(per_sample)),
         ),
         "gan_chan_dot",
     )
-    return out
+    return out if per_sample else out.sum(0)
 
 
 def _pad_channels(x: Tensor, mult: int) -> Tensor:
@@ -284,6 +302,7 @@ def raw_conv2d(
                 ptr(x), ptr(wt), ptr(y), ptr(in_scale), ptr(out_scale32), ptr(bias32), ptr(noise), ptr(ns32), float(slope),
                 n, h, w, cin_p, int(up2), ho, wo, cout, kh, kw, py, px, kpad, dtype_code(x), stream_of(x),
             ),
+            (n, cin, ho, wo, cout, kh, int(up2)),
         ),
         "gan_conv2d_fwd",
     )
@@ -321,6 +340,7 @@ def raw_conv2d_wgrad(
             lambda: lib.gan_conv2d_wgrad(
                 ptr(x), ptr(gy), ptr(dw), ptr(in_scale), n, h, w, cin_p, int(up2), ho, wo, cout_p, kh, kw, py, px, dtype_code(x), stream_of(x)
             ),
+            (n, cin, ho, wo, cout, kh, int(up2)),
         ),
         "gan_conv2d_wgrad",
     )

@@ -284,3 +284,60 @@ def test_ema_lerp_and_mbstd_kernels(dev, golden):
     ref = O.minibatch_stddev(x.double())[:4, -1, 0, 0]
     assert rel_err(GF.raw_mbstd_stat(x.to(dev), 4), ref) < TOL32
     assert rel_err(GF.raw_mbstd_stat(x.to(dev).bfloat16(), 4), ref) < TOLBF
+
+
+THIN_CASES = [
+    # N, Cin, H, W, Cout, k, up2   (bf16, >= 32 wide: served by the halo-tiled direct kernel conv_thin.hip)
+    (2, 16, 64, 64, 16, 3, False),
+    (3, 16, 37, 45, 32, 3, False),  # ragged tiles in both directions
+    (2, 32, 40, 32, 16, 3, False),
+    (2, 32, 24, 40, 16, 3, True),  # nearest-2x fused into the halo loader
+    (1, 32, 64, 96, 32, 3, False),
+    (2, 32, 33, 33, 64, 3, False),
+    (2, 64, 32, 32, 32, 3, False),
+    (1, 64, 20, 24, 32, 3, True),
+    (2, 64, 48, 40, 64, 3, False),
+    (2, 16, 64, 64, 3, 1, False),  # to-RGB: 3 output channels, scalar stores
+    (2, 3, 64, 64, 16, 1, False),  # from-RGB: Cin padded to 8
+    (2, 16, 40, 72, 32, 1, False),  # D shortcut 1x1
+    (2, 64, 32, 64, 3, 1, False),
+    (2, 8, 35, 50, 24, 3, False),
+    (300, 16, 32, 32, 16, 3, False),  # more tiles than resident workgroups: persistent loop takes > 1 tile
+]
+
+
+@pytest.mark.parametrize("case", THIN_CASES)
+def test_conv2d_thin_kernel(dev, case):
+    """Thin-layer direct convolution (bf16) with every fused term, against the fp64 composition."""
+    import gan_amd.functional as GF
+    from oracle import gan_oracle as O
+
+    n, cin, h, w, cout, k, up2 = case
+    torch.manual_seed(11)
+    pad = (k - 1) // 2
+    x = torch.randn(n, cin, h, w).bfloat16()
+    wgt = (torch.randn(cout, cin, k, k) / (cin * k * k) ** 0.5).bfloat16().float()
+    s = torch.randn(n, cin) * 0.5 + 1
+    d = torch.rand(n, cout) + 0.5
+    b = torch.randn(cout)
+    ns = torch.randn(cout)
+    ho, wo = (2 * h, 2 * w) if up2 else (h, w)
+    noise = torch.randn(n, 1, ho, wo).bfloat16()
+    xl = O.nearest_up2(x.double()) if up2 else x.double()
+    xs = (xl * s.double().view(n, cin, 1, 1)).bfloat16().double()  # the kernel rounds the modulated input to bf16
+    ref = F.conv2d(xs, wgt.double(), padding=pad) * d.double().view(n, cout, 1, 1) + b.double().view(1, -1, 1, 1)
+    ref = F.leaky_relu(ref + noise.double() * ns.double().view(1, -1, 1, 1), 0.2)
+    got = GF.raw_conv2d(
+        x.to(dev), wgt.to(dev), pad, pad, up2=up2, in_scale=s.to(dev), out_scale=d.to(dev), bias=b.to(dev),
+        noise=noise.to(dev), noise_scale=ns.to(dev), slope=0.2,
+    )
+    assert got.shape == ref.shape and got.dtype == torch.bfloat16
+    assert rel_err(got, ref) < 4e-3, rel_err(got, ref)  # only the bf16 rounding of the output remains
+    # plain conv (no prologue / epilogue) and its dgrad through the same kernel
+    ref2 = F.conv2d(x.double(), wgt.double(), padding=pad)
+    got2 = GF.raw_conv2d(x.to(dev), wgt.to(dev), pad, pad)
+    assert rel_err(got2, ref2) < 4e-3
+    gy = torch.randn(n, cout, h, w).bfloat16()
+    gx_ref = torch.nn.grad.conv2d_input((n, cin, h, w), wgt.double(), gy.double(), padding=pad)
+    gx = GF.raw_conv2d_dgrad(gy.to(dev), wgt.to(dev), pad, pad)
+    assert rel_err(gx, gx_ref) < 4e-3
