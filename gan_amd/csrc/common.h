@@ -98,4 +98,9 @@ int gan_conv2d_fwd_thin(const void* x, const void* wt, void* y, const float* in_
                         int W, int Cin, int up2, int Ho, int Wo, int Cout, int kh, int kw, int py, int px, int Kpad,
                         hipStream_t st);
 
+// conv_thin_wgrad.hip: weight gradient for thin layers (bf16); dw must be zeroed by the caller.
+int gan_conv2d_wgrad_thin(const void* x, const void* gy, float* dw, const float* in_scale, int N, int H, int W,
+                          int Cin, int up2, int Ho, int Wo, int Cout, int kh, int kw, int py, int px,
+                          hipStream_t st);
+
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }

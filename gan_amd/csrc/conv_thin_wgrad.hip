@@ -1,0 +1,235 @@
+// Weight gradient for THIN layers on MFMA (gfx950): Cin, Cout <= 64 at large spatial size, bf16.
+//
+//   dw[tap][co][ci] = sum_{n,oy,ox} gy[n,oy,ox,co] * X[n, oy+dy-py, ox+dx-px, ci] * in_scale[n][ci]
+//
+// Like the forward thin kernel (conv_thin.hip) this shape is HBM-bound (gy and x are each read once
+// from HBM in the ideal), so: a persistent workgroup walks a contiguous range of TH x 32 pixel
+// tiles; per tile the gy tile and the (TH+2) x 34 halo of x go to LDS ONCE with 16-byte loads
+// (nearest-2x upsampling and style modulation applied on the way) and all kh*kw taps are formed from
+// that one LDS image; accumulators for every tap live in registers across ALL tiles of the
+// workgroup and are flushed with one fp32 atomic per element at the end.
+//
+// MFMA view (16x16x32 bf16): rows = co, cols = ci, k = 32 pixels = one tile row.  Both operands
+// are pixel-major in memory, i.e. transposed for MFMA fragments; they are stored in LDS as
+// [16-channel group][pixel][16 ch] (32-byte rows) and read with ds_read_b64_tr_b16, k <-> pixel
+// map  k = 8g + j  <->  x = (j < 4 ? 4g + j : 16 + 4g + j - 4)  so that one instruction touches 16
+// consecutive 32-byte rows (conflict-free).  Waves split the work as WR row groups x WT tap groups
+// so that the per-wave accumulator set (taps x Cout/16 x Cin/16 x 4 registers) fits.
+#include "common.h"
+
+namespace {
+
+struct ThinWArgs {
+    const void* x;
+    const void* gy;
+    float* dw;
+    const float* in_scale;
+    int N, H, W, Hl, Wl, up2, Ho, Wo, Cin, Cout, py, px;
+    int tiles_x, tiles_y;
+};
+
+__device__ __forceinline__ uint4 wmod_chunk(uint4 raw, const float* s) {
+    bf16x8 v = *reinterpret_cast<bf16x8*>(&raw);
+    const float4 s0 = *reinterpret_cast<const float4*>(s);
+    const float4 s1 = *reinterpret_cast<const float4*>(s + 4);
+    v[0] = (bf16)((float)v[0] * s0.x);
+    v[1] = (bf16)((float)v[1] * s0.y);
+    v[2] = (bf16)((float)v[2] * s0.z);
+    v[3] = (bf16)((float)v[3] * s0.w);
+    v[4] = (bf16)((float)v[4] * s1.x);
+    v[5] = (bf16)((float)v[5] * s1.y);
+    v[6] = (bf16)((float)v[6] * s1.z);
+    v[7] = (bf16)((float)v[7] * s1.w);
+    return *reinterpret_cast<uint4*>(&v);
+}
+
+// 8 pixels (k = 8g .. 8g+7 under the map above) of channel (lane & 15) of a [pixel][16 ch] LDS image;
+// `p` already points at this lane's 8-byte piece of row (4g + q) of the 32-pixel run.
+__device__ __forceinline__ bf16x8 tr_frag(const char* p) {
+    typedef bf16x4 __attribute__((address_space(3))) * lds_ptr;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_ptr)p);
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_ptr)(p + 16 * 32));
+    bf16x8 f;
+    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+    f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+    return f;
+}
+
+template <int CIN, int COUT, int KS, int TH, int WT>
+struct ThinWCfg {
+    static constexpr int CGI = CIN / 16, CGO = COUT / 16;
+    static constexpr int HH = TH + KS - 1, HWD = 32 + KS - 1, NPX = HH * HWD, NPG = TH * 32;
+    static constexpr int PLX = NPX * 32, PLG = NPG * 32;  // bytes per 16-channel plane
+    static constexpr int WR = 4 / WT, ROWS = TH / WR, NT = (KS * KS + WT - 1) / WT;
+    static constexpr int NCX = ((NPX + 7) / 8) * 8 * (CIN / 8), NCG = NPG * (COUT / 8);
+    static constexpr int X_BYTES = CGI * PLX, G_BYTES = CGO * PLG, LDS_BYTES = X_BYTES + G_BYTES;
+};
+
+template <int CIN, int COUT, int KS, int TH, int WT>
+__global__ void __launch_bounds__(256) conv_thin_wgrad_k(const ThinWArgs p) {
+    typedef ThinWCfg<CIN, COUT, KS, TH, WT> C;
+    constexpr int CGI = C::CGI, CGO = C::CGO, HWD = C::HWD, NPX = C::NPX, PLX = C::PLX, PLG = C::PLG;
+    constexpr int ROWS = C::ROWS, NT = C::NT, CPX = CIN / 8, CPG = COUT / 8;
+
+    __shared__ __attribute__((aligned(256))) char lds[C::LDS_BYTES];
+    char* const xl = lds;
+    char* const gl = lds + C::X_BYTES;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wt = wave % WT, wr = wave / WT;
+    const bf16* __restrict__ x = (const bf16*)p.x;
+    const bf16* __restrict__ gy = (const bf16*)p.gy;
+
+    const int tiles_per_img = p.tiles_x * p.tiles_y;
+    const int64_t ntiles = (int64_t)tiles_per_img * p.N;
+    const int64_t t0 = ntiles * blockIdx.x / gridDim.x;
+    const int64_t t1 = ntiles * (blockIdx.x + 1) / gridDim.x;
+
+    f32x4 acc[NT][CGO][CGI];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int o = 0; o < CGO; ++o)
+#pragma unroll
+            for (int i = 0; i < CGI; ++i) acc[j][o][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int g = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
+    const int lane_off = (4 * g + q) * 32 + pp * 8;  // this lane's piece inside a 32-pixel run
+
+    for (int64_t t = t0; t < t1; ++t) {
+        const int n = (int)(t / tiles_per_img);
+        const int rem = (int)(t - (int64_t)n * tiles_per_img);
+        const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
+        const int oy0 = ty * TH, ox0 = tx * 32;
+        __syncthreads();  // previous tile's fragment reads are done
+        // ---- x halo -> LDS [ci/16][pixel][16] ------------------------------------------------
+        for (int idx = tid; idx < C::NCX; idx += 256) {
+            const int p8 = idx / (8 * CPX), r8 = idx % (8 * CPX);
+            const int c8 = r8 >> 3;
+            const int pix = p8 * 8 + (r8 & 7);
+            if (pix >= NPX) continue;
+            const int hy = pix / HWD, hx = pix - hy * HWD;
+            const int ly = oy0 - p.py + hy, lx = ox0 - p.px + hx;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if ((unsigned)ly < (unsigned)p.Hl && (unsigned)lx < (unsigned)p.Wl && c8 * 8 < p.Cin) {
+                const int64_t off = (((int64_t)n * p.H + (ly >> p.up2)) * p.W + (lx >> p.up2)) * p.Cin + c8 * 8;
+                v = *reinterpret_cast<const uint4*>(x + off);
+                if (p.in_scale) v = wmod_chunk(v, p.in_scale + (int64_t)n * p.Cin + c8 * 8);
+            }
+            *reinterpret_cast<uint4*>(xl + (c8 >> 1) * PLX + pix * 32 + (c8 & 1) * 16) = v;
+        }
+        // ---- gy tile -> LDS [co/16][pixel][16] ------------------------------------------------
+        for (int idx = tid; idx < C::NCG; idx += 256) {
+            const int p8 = idx / (8 * CPG), r8 = idx % (8 * CPG);
+            const int c8 = r8 >> 3;
+            const int pix = p8 * 8 + (r8 & 7);
+            const int ry = pix >> 5, rx = pix & 31;
+            const int oy = oy0 + ry, ox = ox0 + rx;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (oy < p.Ho && ox < p.Wo && c8 * 8 < p.Cout)
+                v = *reinterpret_cast<const uint4*>(gy + (((int64_t)n * p.Ho + oy) * p.Wo + ox) * p.Cout + c8 * 8);
+            *reinterpret_cast<uint4*>(gl + (c8 >> 1) * PLG + pix * 32 + (c8 & 1) * 16) = v;
+        }
+        __syncthreads();
+
+#pragma unroll 1
+        for (int rr = 0; rr < ROWS; ++rr) {
+            const int r = wr * ROWS + rr;
+            bf16x8 a[CGO];
+#pragma unroll
+            for (int o = 0; o < CGO; ++o) a[o] = tr_frag(gl + o * PLG + r * 32 * 32 + lane_off);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int tap = wt + j * WT;
+                if (tap < KS * KS) {
+                    const int dy = tap / KS, dx = tap - dy * KS;
+                    const char* const xb = xl + ((r + dy) * HWD + dx) * 32 + lane_off;
+#pragma unroll
+                    for (int i = 0; i < CGI; ++i) {
+                        const bf16x8 b = tr_frag(xb + i * PLX);
+#pragma unroll
+                        for (int o = 0; o < CGO; ++o)
+                            acc[j][o][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[o], b, acc[j][o][i], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- flush: D layout col = lane & 15 -> ci, row = 4*(lane >> 4) + r -> co ----------------------
+    if (t0 < t1) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int tap = wt + j * WT;
+            if (tap >= KS * KS) continue;
+            float* __restrict__ dwt = p.dw + (int64_t)tap * p.Cout * p.Cin;
+#pragma unroll
+            for (int o = 0; o < CGO; ++o)
+#pragma unroll
+                for (int i = 0; i < CGI; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int co = o * 16 + g * 4 + r;
+                        const int ci = i * 16 + li;
+                        if (co < p.Cout && ci < p.Cin) atomicAdd(dwt + (int64_t)co * p.Cin + ci, acc[j][o][i][r]);
+                    }
+        }
+    }
+}
+
+template <int CIN, int COUT, int KS, int TH, int WT>
+int launch_thin_w(ThinWArgs a, hipStream_t st) {
+    typedef ThinWCfg<CIN, COUT, KS, TH, WT> C;
+    static_assert(C::LDS_BYTES <= 160 * 1024, "tile does not fit LDS");
+    static_assert(TH % C::WR == 0, "rows must split evenly over the row groups");
+    a.tiles_x = (a.Wo + 31) / 32;
+    a.tiles_y = (a.Ho + TH - 1) / TH;
+    const int64_t ntiles = (int64_t)a.tiles_x * a.tiles_y * a.N;
+    int per_cu = (160 * 1024) / C::LDS_BYTES;
+    if (per_cu > 4) per_cu = 4;
+    if (per_cu < 1) per_cu = 1;
+    int64_t grid = 256LL * per_cu;
+    if (grid > ntiles) grid = ntiles;
+    hipLaunchKernelGGL((conv_thin_wgrad_k<CIN, COUT, KS, TH, WT>), dim3((unsigned)grid), dim3(256), 0, st, a);
+    GAN_CHECK_LAUNCH("conv2d_wgrad(thin)");
+    return GAN_OK;
+}
+
+template <int CIN, int COUT>
+int pick_ks(const ThinWArgs& a, int ks, hipStream_t st) {
+    constexpr int F = (CIN / 16) * (COUT / 16);
+    constexpr int TH = (CIN <= 16 && COUT <= 32) ? 16 : 8;
+    if (ks == 1) return launch_thin_w<CIN, COUT, 1, TH, 1>(a, st);
+    constexpr int WT = F <= 4 ? 1 : (F <= 8 ? 2 : 4);
+    return launch_thin_w<CIN, COUT, 3, TH, WT>(a, st);
+}
+
+template <int CIN>
+int pick_cout_w(const ThinWArgs& a, int ks, hipStream_t st) {
+    if (a.Cout <= 16) return pick_ks<CIN, 16>(a, ks, st);
+    if (a.Cout <= 32) return pick_ks<CIN, 32>(a, ks, st);
+    return pick_ks<CIN, 64>(a, ks, st);
+}
+
+}  // namespace
+
+// 1 = served (dw must already be zeroed), 0 = shape not eligible, < 0 = error.
+int gan_conv2d_wgrad_thin(const void* x, const void* gy, float* dw, const float* in_scale, int N, int H, int W,
+                          int Cin, int up2, int Ho, int Wo, int Cout, int kh, int kw, int py, int px,
+                          hipStream_t st) {
+    if (kh != kw || (kh != 1 && kh != 3)) return 0;
+    if (py != (kh - 1) / 2 || px != py) return 0;
+    if (Cin > 64 || Cout > 64 || (Cin & 7) || (Cout & 7) || Wo < 32 || Ho < 8) return 0;
+    ThinWArgs a;
+    a.x = x; a.gy = gy; a.dw = dw; a.in_scale = in_scale;
+    a.N = N; a.H = H; a.W = W; a.Hl = up2 ? 2 * H : H; a.Wl = up2 ? 2 * W : W; a.up2 = up2;
+    a.Ho = Ho; a.Wo = Wo; a.Cin = Cin; a.Cout = Cout; a.py = py; a.px = px;
+    a.tiles_x = a.tiles_y = 0;
+    int rc;
+    if (Cin <= 16) rc = pick_cout_w<16>(a, kh, st);
+    else if (Cin <= 32) rc = pick_cout_w<32>(a, kh, st);
+    else rc = pick_cout_w<64>(a, kh, st);
+    return rc == GAN_OK ? 1 : rc;
+}

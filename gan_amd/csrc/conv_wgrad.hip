@@ -264,5 +264,7 @@ extern "C" int gan_conv2d_wgrad(const void* x, const void* gy, float* dw, const 
     a.M = (int64_t)N * Ho * Wo;
     a.pix_per_split = 128;
     if (dtype == GAN_F32) return launch<float>(a, st);
+    const int thin = gan_conv2d_wgrad_thin(x, gy, dw, in_scale, N, H, W, Cin, up2, Ho, Wo, Cout, kh, kw, py, px, st);
+    if (thin != 0) return thin < 0 ? thin : GAN_OK;
     return launch<bf16>(a, st);
 }

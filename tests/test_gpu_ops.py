@@ -341,3 +341,27 @@ def test_conv2d_thin_kernel(dev, case):
     gx_ref = torch.nn.grad.conv2d_input((n, cin, h, w), wgt.double(), gy.double(), padding=pad)
     gx = GF.raw_conv2d_dgrad(gy.to(dev), wgt.to(dev), pad, pad)
     assert rel_err(gx, gx_ref) < 4e-3
+
+
+@pytest.mark.parametrize("case", THIN_CASES)
+def test_conv2d_thin_wgrad_kernel(dev, case):
+    """Thin-layer weight gradient (bf16; modulation and nearest-2x fused into its staging) against fp64."""
+    import gan_amd.functional as GF
+    from oracle import gan_oracle as O
+
+    n, cin, h, w, cout, k, up2 = case
+    torch.manual_seed(12)
+    pad = (k - 1) // 2
+    x = torch.randn(n, cin, h, w).bfloat16()
+    s = torch.randn(n, cin) * 0.5 + 1
+    ho, wo = (2 * h, 2 * w) if up2 else (h, w)
+    gy = torch.randn(n, cout, ho, wo).bfloat16()
+    xl = O.nearest_up2(x.double()) if up2 else x.double()
+    xs = (xl * s.double().view(n, cin, 1, 1)).bfloat16().double()
+    ref = torch.nn.grad.conv2d_weight(xs, (cout, cin, k, k), gy.double(), padding=pad)
+    got = GF.raw_conv2d_wgrad(x.to(dev), gy.to(dev), k, k, pad, pad, up2=up2, in_scale=s.to(dev))
+    assert got.shape == ref.shape and got.dtype == torch.float32
+    assert rel_err(got, ref) < 1e-4, rel_err(got, ref)  # exact bf16 products, fp32 accumulation
+    ref2 = torch.nn.grad.conv2d_weight(x.double(), (cout, cin, k, k), gy[:, :, :h, :w].double(), padding=pad)
+    got2 = GF.raw_conv2d_wgrad(x.to(dev), gy[:, :, :h, :w].contiguous().to(dev), k, k, pad, pad)
+    assert rel_err(got2, ref2) < 1e-4, rel_err(got2, ref2)
