@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--no_cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no_micro", action="store_true", help="skip the upfirdn2d microbenchmark leg")
     ap.add_argument("--no_roofline", action="store_true")
+    ap.add_argument("--micro_only", action="store_true", help="run only the upfirdn2d microbenchmark leg and print it")
     return ap.parse_args()
 
 
@@ -190,6 +191,9 @@ def main():
     from gan_amd.train_celeba import synthetic_reals
 
     rank, world, device = init_from_env("cuda")
+    if args.micro_only:
+        print(json.dumps(micro_leg(device)), flush=True)
+        return
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE is {world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if args.global_batch % (4 * world) != 0:

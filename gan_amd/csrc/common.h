@@ -103,4 +103,8 @@ int gan_conv2d_wgrad_thin(const void* x, const void* gy, float* dw, const float*
                           int Cin, int up2, int Ho, int Wo, int Cout, int kh, int kw, int py, int px,
                           hipStream_t st);
 
+// upfirdn_mfma.hip: bf16 upfirdn2d with the FIR as banded matrix products on MFMA.  1 / 0 / < 0 as above.
+int gan_upfirdn2d_mfma(const void* x, const float* taps, void* y, int N, int H, int W, int C, int ky, int kx, int up,
+                       int down, int px1, int py1, int Ho, int Wo, hipStream_t st);
+
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }

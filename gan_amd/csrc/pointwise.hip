@@ -52,6 +52,84 @@ __global__ void __launch_bounds__(TPB) upfirdn2d_k(const T* __restrict__ x, cons
     store_f<T, V>(y + idx * V, acc);
 }
 
+// LDS-tiled form (C a multiple of the 16-byte vector): a workgroup owns TH x 32 output pixels x NVB
+// channel vectors.  The input region those outputs touch is read from HBM once with 16-byte loads into
+// LDS ([row][col][vector]); every tap is then an LDS read, so HBM sees ~(1 + halo) x the input instead
+// of each tap missing L1 separately.
+template <typename T, int V>
+__global__ void __launch_bounds__(TPB) upfirdn2d_tile_k(const T* __restrict__ x, const float* __restrict__ taps,
+                                                        T* __restrict__ y, int H, int W, int C, int ky, int kx,
+                                                        int up, int down, int px1, int py1, int Ho, int Wo, int TH,
+                                                        int nvb_log2, int tiles_x, int RWmax) {
+    extern __shared__ __attribute__((aligned(16))) char tile_lds[];
+    __shared__ float tap_lds[256];
+    const int tid = threadIdx.x;
+    const int NVB = 1 << nvb_log2;
+    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+    const int vb = blockIdx.y;
+    const int64_t n = blockIdx.z;
+    const int oy0 = ty * TH, ox0 = tx * 32;
+    const int th = min(TH, Ho - oy0), tw = min(32, Wo - ox0);
+
+    for (int i = tid; i < ky * kx; i += TPB) tap_lds[i] = taps[i];
+
+    // input region [iy_lo, iy_hi] x [ix_lo, ix_hi] touched by this tile (clamped to the image)
+    const int by0 = oy0 * down - py1, bx0 = ox0 * down - px1;
+    int iy_lo = by0 >= 0 ? (by0 + up - 1) / up : -((-by0) / up);
+    int ix_lo = bx0 >= 0 ? (bx0 + up - 1) / up : -((-bx0) / up);
+    const int ey = (oy0 + th - 1) * down - py1 + ky - 1, ex = (ox0 + tw - 1) * down - px1 + kx - 1;
+    int iy_hi = ey >= 0 ? ey / up : -1, ix_hi = ex >= 0 ? ex / up : -1;
+    iy_lo = max(iy_lo, 0);
+    ix_lo = max(ix_lo, 0);
+    iy_hi = min(iy_hi, H - 1);
+    ix_hi = min(ix_hi, W - 1);
+    const int RH = iy_hi - iy_lo + 1, RW = ix_hi - ix_lo + 1;
+    if (RH > 0 && RW > 0) {
+        const int rowv = RW << nvb_log2;
+        const int total = RH * rowv;
+        const T* __restrict__ xb = x + ((n * H + iy_lo) * W + ix_lo) * C + (int64_t)vb * NVB * V;
+        for (int idx = tid; idx < total; idx += TPB) {
+            const int ry = idx / rowv, rem = idx - ry * rowv;
+            const int rx = rem >> nvb_log2, v = rem & (NVB - 1);
+            const uint4 q = *reinterpret_cast<const uint4*>(xb + ((int64_t)ry * W + rx) * C + v * V);
+            *reinterpret_cast<uint4*>(tile_lds + ((ry * RWmax + rx) * NVB + v) * 16) = q;
+        }
+    }
+    __syncthreads();
+
+    const int outs = (th * 32) << nvb_log2;
+    for (int idx = tid; idx < outs; idx += TPB) {
+        const int v = idx & (NVB - 1);
+        const int pix = idx >> nvb_log2;
+        const int ox_l = pix & 31, oy_l = pix >> 5;
+        if (ox_l >= tw) continue;
+        const int oy = oy0 + oy_l, ox = ox0 + ox_l;
+        const int by = oy * down - py1, bx = ox * down - px1;
+        int i0 = (-by) % up;
+        if (i0 < 0) i0 += up;
+        int j0 = (-bx) % up;
+        if (j0 < 0) j0 += up;
+        float acc[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) acc[e] = 0.f;
+        for (int i = i0; i < ky; i += up) {
+            const int iy = (by + i) / up;
+            if (iy < iy_lo || iy > iy_hi) continue;
+            const char* rowp = tile_lds + (((iy - iy_lo) * RWmax - ix_lo) * NVB + v) * 16;
+            for (int j = j0; j < kx; j += up) {
+                const int ix = (bx + j) / up;
+                if (ix < ix_lo || ix > ix_hi) continue;
+                const float t = tap_lds[i * kx + j];
+                float vv[V];
+                load_f<T, V>(reinterpret_cast<const T*>(rowp + ix * NVB * 16), vv);
+#pragma unroll
+                for (int e = 0; e < V; ++e) acc[e] = fmaf(t, vv[e], acc[e]);
+            }
+        }
+        store_f<T, V>(y + ((n * Ho + oy) * Wo + ox) * C + ((int64_t)vb * NVB + v) * V, acc);
+    }
+}
+
 template <typename T>
 static int upfirdn2d_launch(const void* x, const float* taps, void* y, int N, int H, int W, int C, int ky, int kx,
                             int up, int down, int px1, int py1, int Ho, int Wo, hipStream_t st) {
@@ -59,6 +137,31 @@ static int upfirdn2d_launch(const void* x, const float* taps, void* y, int N, in
     const bool vec = (C % VV) == 0;
     const int64_t total = (int64_t)N * Ho * Wo * (vec ? C / VV : C);
     if (total == 0) return GAN_OK;
+    if constexpr (sizeof(T) == 2) {
+        const int rc = gan_upfirdn2d_mfma(x, taps, y, N, H, W, C, ky, kx, up, down, px1, py1, Ho, Wo, st);
+        if (rc != 0) return rc < 0 ? rc : GAN_OK;
+    }
+    if (vec && ky * kx <= 256 && N <= 65535 && Wo >= 8) {
+        const int cv = C / VV;
+        int nvb_log2 = 0;
+        while (nvb_log2 < 3 && (cv % (2 << nvb_log2)) == 0) ++nvb_log2;
+        const int NVB = 1 << nvb_log2;
+        // rows per tile: as many as keep the LDS region under 48 KiB (at least 1), at most 8
+        const int RWmax = (31 * down + kx - 1) / up + 2;
+        int TH = 8;
+        auto region_bytes = [&](int th) { return (((th - 1) * down + ky - 1) / up + 2) * RWmax * NVB * 16; };
+        while (TH > 1 && region_bytes(TH) > 48 * 1024) TH >>= 1;
+        if (TH > Ho) TH = Ho;
+        const int lds = region_bytes(TH);
+        const int tiles_x = (Wo + 31) / 32, tiles_y = (Ho + TH - 1) / TH;
+        if (lds <= 64 * 1024 && (int64_t)tiles_x * tiles_y < (1LL << 31) && cv / NVB <= 65535) {
+            hipLaunchKernelGGL((upfirdn2d_tile_k<T, VV>), dim3((unsigned)(tiles_x * tiles_y), (unsigned)(cv / NVB), (unsigned)N),
+                               dim3(TPB), (size_t)lds, st, (const T*)x, taps, (T*)y, H, W, C, ky, kx, up, down, px1, py1,
+                               Ho, Wo, TH, nvb_log2, tiles_x, RWmax);
+            GAN_CHECK_LAUNCH("upfirdn2d(tile)");
+            return GAN_OK;
+        }
+    }
     const int64_t blocks = ceil_div64(total, TPB);
     GAN_CHECK_ARG(blocks < (1LL << 31), "upfirdn2d: tensor too large");
     if (vec)

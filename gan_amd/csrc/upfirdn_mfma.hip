@@ -1,0 +1,201 @@
+// upfirdn2d for bf16 channels-last tensors with the FIR evaluated on the matrix cores (gfx950).
+//
+// The op (modelling/nvidia_ops.py:18-34) is HBM-bound -- (numel_in + numel_out) * 2 bytes per call --
+// but a straight VALU evaluation is not: 9 taps x 8 channels need ~16 VALU instructions per tap
+// vector (bf16 -> fp32 unpack + fma), which caps a 3x3 FIR near 2.4 TB/s on MI355X (measured).  The
+// matrix pipe has 16x the rate, and a 1-D FIR along x is a banded (Toeplitz) matrix product:
+//
+//   out[c][xo] = sum_i sum_xi  X_i[c][xi] * T_i[xi][xo],      T_i[xi][xo] = t[i][xi*up + px1 - xo*down]
+//
+// one v_mfma_f32_16x16x32_bf16 per (kernel row i, 16 channels, 16 output pixels), K = 32 input pixels.
+// fp32 taps are split into bf16 hi + lo parts (two MFMAs), products are exact, accumulation is fp32,
+// so the result matches the fp32-tap reference to ~1e-5.  Zero insertion (up), the stride (down) and
+// the padding all live in the band structure of T; vertical polyphase skips the rows whose taps hit
+// inserted zeros.  A = X^T is read from a [16-channel group][pixel][16 ch] LDS image with
+// ds_read_b64_tr_b16 (the k <-> pixel map of conv_thin_wgrad.hip); D comes out as 4 consecutive
+// channels of one pixel per lane -> 8-byte stores, 512 contiguous bytes per wave at C = 16.
+#include "common.h"
+
+namespace {
+
+struct FirArgs {
+    const bf16* x;
+    const float* taps;
+    bf16* y;
+    int H, W, C, ky, kx, up_log2, down, px1, py1, Ho, Wo;
+    int TH, ncg_log2, KC, RWr, RHmax, tiles_x, tiles_y, xstep, ncols, ncb;
+    int64_t ntiles;
+};
+
+__device__ __forceinline__ bf16x8 fir_tr_frag(const char* p) {
+    typedef bf16x4 __attribute__((address_space(3))) * lds_ptr;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_ptr)p);
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_ptr)(p + 16 * 32));
+    bf16x8 f;
+    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+    f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+    return f;
+}
+
+
+__global__ void __launch_bounds__(256, 4) upfirdn2d_mfma_k(const FirArgs p) {
+    extern __shared__ __attribute__((aligned(256))) char fir_lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
+    const int up = 1 << p.up_log2, down = p.down;
+    const int ncg = 1 << p.ncg_log2;
+    char* const toep = fir_lds;                                  // [ky][KC][hi,lo][64 lanes][16 B]
+    char* const reg = fir_lds + p.ky * p.KC * 2048;              // [ncg][RHmax * RWr pixels][32 B]
+    const int PL = p.RHmax * p.RWr * 32;
+
+    // ---- banded tap matrices, in MFMA B-fragment order (once per workgroup) ------------------------
+    const int J0 = p.px1 & (up - 1);
+    for (int e = tid; e < p.ky * p.KC * 64; e += 256) {
+        const int l = e & 63, kc = (e >> 6) % p.KC, i = (e >> 6) / p.KC;
+        const int xo = l & 15, gg = l >> 4;
+        bf16x8 hi, lo;
+#pragma unroll
+        for (int j8 = 0; j8 < 8; ++j8) {
+            const int xrel = 32 * kc + (j8 < 4 ? 4 * gg + j8 : 16 + 4 * gg + j8 - 4);
+            const int j = xrel * up - xo * down + J0;
+            const float t = (j >= 0 && j < p.kx) ? p.taps[i * p.kx + j] : 0.f;
+            hi[j8] = (bf16)t;
+            lo[j8] = (bf16)(t - (float)hi[j8]);
+        }
+        char* dst = toep + ((i * p.KC + kc) * 2) * 1024 + l * 16;
+        *reinterpret_cast<bf16x8*>(dst) = hi;
+        *reinterpret_cast<bf16x8*>(dst + 1024) = lo;
+    }
+
+    // ---- persistent walk over a contiguous range of tiles: t -> (n, channel block, ty, tx) ---------
+    const int64_t t0 = p.ntiles * blockIdx.x / gridDim.x;
+    const int64_t t1 = p.ntiles * (blockIdx.x + 1) / gridDim.x;
+    const int CP = ncg * 2;
+    const int tiles_per_cb = p.tiles_x * p.tiles_y;
+
+    auto decode = [&](int64_t t, int& n, int& cb, int& oy0, int& ox0) {
+        const int64_t img = t / tiles_per_cb;
+        const int rem = (int)(t - img * tiles_per_cb);
+        n = (int)(img / p.ncb);
+        cb = (int)(img - (int64_t)n * p.ncb);
+        const int ty = rem / p.tiles_x;
+        oy0 = ty * p.TH;
+        ox0 = (rem - ty * p.tiles_x) * 32;
+    };
+    // input region (zero outside the image and in the columns that only meet zero taps) -> LDS
+    auto load_region = [&](int n, int cb, int oy0, int ox0, int iy0) {
+        const int bx0 = ox0 * down - p.px1;
+        const int ix0 = (bx0 + up - 1) >> p.up_log2;
+        const int iy1 = ((oy0 + p.TH - 1) * down - p.py1 + p.ky - 1) >> p.up_log2;
+        const int npix = (iy1 - iy0 + 1) * p.RWr;
+        const int nchunk = ((npix + 7) >> 3) * 8 * CP;
+        const bf16* __restrict__ xb = p.x + (int64_t)cb * ncg * 16;
+        for (int idx = tid; idx < nchunk; idx += 256) {
+            const int p8 = idx / (8 * CP), r8 = idx - p8 * 8 * CP;
+            const int c8 = r8 >> 3;
+            const int pix = p8 * 8 + (r8 & 7);
+            if (pix >= npix) continue;
+            const int ry = pix / p.RWr, rx = pix - ry * p.RWr;
+            const int iy = iy0 + ry, ix = ix0 + rx;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (rx < p.ncols && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+                v = *reinterpret_cast<const uint4*>(xb + (((int64_t)n * p.H + iy) * p.W + ix) * p.C + c8 * 8);
+            *reinterpret_cast<uint4*>(reg + (c8 >> 1) * PL + pix * 32 + (c8 & 1) * 16) = v;
+        }
+    };
+
+    const int rows_per_wave = 4 >> p.ncg_log2;
+    const int lane_off = (4 * g + q) * 32 + pp * 8;
+    for (int64_t t = t0; t < t1; ++t) {
+        int n, cb, oy0, ox0;
+        decode(t, n, cb, oy0, ox0);
+        const int iy0 = (oy0 * down - p.py1 + up - 1) >> p.up_log2;
+        __syncthreads();  // previous tile's fragment reads (and the tap matrices' stores) are done
+        load_region(n, cb, oy0, ox0, iy0);
+        __syncthreads();
+        // 8 output fragments (16 ch x 16 px) per wave: f -> (row, x half, channel group)
+        f32x4 acc[8];
+#pragma unroll
+        for (int f = 0; f < 8; ++f) acc[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < p.ky; ++i) {
+            for (int kc = 0; kc < p.KC; ++kc) {
+                const char* tp = toep + ((i * p.KC + kc) * 2) * 1024 + lane * 16;
+                const bf16x8 bhi = *reinterpret_cast<const bf16x8*>(tp);
+                const bf16x8 blo = *reinterpret_cast<const bf16x8*>(tp + 1024);
+#pragma unroll
+                for (int f = 0; f < 8; ++f) {
+                    const int cgi = f & (ncg - 1);
+                    const int fx = (f >> p.ncg_log2) & 1;
+                    const int rl = wave * rows_per_wave + (f >> (p.ncg_log2 + 1));
+                    const int by = (oy0 + rl) * down - p.py1 + i;
+                    if (by & (up - 1)) continue;  // this tap row falls on inserted zeros (wave-uniform)
+                    const int ry = (by >> p.up_log2) - iy0;
+                    const bf16x8 a = fir_tr_frag(reg + cgi * PL + (ry * p.RWr + fx * p.xstep + 32 * kc) * 32 + lane_off);
+                    acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bhi, acc[f], 0, 0, 0);
+                    acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, blo, acc[f], 0, 0, 0);
+                }
+            }
+        }
+        // D: row = channel 4g + r, col = output pixel li -> 8-byte stores
+#pragma unroll
+        for (int f = 0; f < 8; ++f) {
+            const int cgi = f & (ncg - 1);
+            const int fx = (f >> p.ncg_log2) & 1;
+            const int oy = oy0 + wave * rows_per_wave + (f >> (p.ncg_log2 + 1));
+            const int ox = ox0 + 16 * fx + li;
+            if (oy >= p.Ho || ox >= p.Wo) continue;
+            bf16x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = (bf16)acc[f][r];
+            *reinterpret_cast<bf16x4*>(p.y + (((int64_t)n * p.Ho + oy) * p.Wo + ox) * p.C + (cb * ncg + cgi) * 16 + 4 * g) = o;
+        }
+    }
+}
+
+}  // namespace
+
+// 1 = served, 0 = shape not eligible (caller falls back to the VALU kernels), < 0 = error.
+int gan_upfirdn2d_mfma(const void* x, const float* taps, void* y, int N, int H, int W, int C, int ky, int kx, int up,
+                       int down, int px1, int py1, int Ho, int Wo, hipStream_t st) {
+    if ((C & 15) || (up != 1 && up != 2) || (down != 1 && down != 2)) return 0;
+    if (Wo < 16 || Ho < 2 || ky > 16 || kx > 16 || N > 65535 || C / 16 > 65535) return 0;
+    if ((((uintptr_t)x) & 15) || (((uintptr_t)y) & 7)) return 0;
+    const int kneed = (15 * down + kx - 1) / up;  // largest input offset inside a 16-pixel output group
+    if (kneed > 63) return 0;
+    FirArgs a;
+    a.x = (const bf16*)x; a.taps = taps; a.y = (bf16*)y;
+    a.H = H; a.W = W; a.C = C; a.ky = ky; a.kx = kx; a.up_log2 = up == 2 ? 1 : 0; a.down = down;
+    a.px1 = px1; a.py1 = py1; a.Ho = Ho; a.Wo = Wo;
+    a.KC = kneed > 31 ? 2 : 1;
+    a.xstep = 16 * down / up;
+    a.RWr = 32 * a.KC + a.xstep;
+    a.ncols = a.xstep + kneed + 1;
+    int lds = 0;
+    int ncg_log2 = 2;
+    for (;; --ncg_log2) {
+        const int ncg = 1 << ncg_log2;
+        if ((C / 16) % ncg == 0) {
+            a.TH = 16 >> ncg_log2;
+            a.RHmax = ((a.TH - 1) * down + ky - 1) / up + 2;
+            lds = ky * a.KC * 2048 + ncg * a.RHmax * a.RWr * 32;
+            if (lds <= 40 * 1024) break;  // >= 4 workgroups per CU: their load / MFMA phases overlap
+        }
+        if (ncg_log2 == 0) return 0;
+    }
+    a.ncg_log2 = ncg_log2;
+    a.tiles_x = (Wo + 31) / 32;
+    a.tiles_y = (Ho + a.TH - 1) / a.TH;
+    a.ncb = C / 16 >> ncg_log2;
+    a.ntiles = (int64_t)a.tiles_x * a.tiles_y * a.ncb * N;
+    int per_cu = (160 * 1024) / lds;
+    if (per_cu > 4) per_cu = 4;
+    int64_t grid = 256LL * per_cu;
+    if (grid > a.ntiles) grid = a.ntiles;
+    hipLaunchKernelGGL(upfirdn2d_mfma_k, dim3((unsigned)grid), dim3(256), (size_t)lds, st, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        gan_set_error("upfirdn2d(mfma): launch failed: %s", hipGetErrorString(e));
+        return GAN_ERR_LAUNCH;
+    }
+    return 1;
+}

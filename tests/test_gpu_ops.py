@@ -76,7 +76,7 @@ def test_upfirdn2d_blur_identities(dev, golden):
         assert rel_err(Blur(k, u, d).to(dev)(xb), ref) < TOL32, key
 
 
-@pytest.mark.parametrize("shape", [(2, 16, 9, 7), (1, 8, 32, 32), (3, 24, 5, 5), (2, 3, 8, 8), (2, 513, 4, 4)])
+@pytest.mark.parametrize("shape", [(2, 16, 9, 7), (1, 8, 32, 32), (3, 24, 5, 5), (2, 3, 8, 8), (2, 513, 4, 4), (2, 16, 19, 45), (1, 64, 40, 33), (2, 24, 16, 16), (1, 128, 9, 70)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_upfirdn2d_shapes_dtypes(dev, shape, dtype):
     from oracle import gan_oracle as O
