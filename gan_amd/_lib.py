@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgan_amd.so")
 
 GAN_F32, GAN_BF16 = 0, 1
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _SIGNATURES = {
     "gan_amd_version": (c_int, []),
@@ -37,7 +37,8 @@ _SIGNATURES = {
         c_int,
         [c_void_p] * 8 + [c_float] + [c_int] * 14 + [c_void_p],
     ),
-    "gan_conv2d_wgrad": (c_int, [c_void_p] * 4 + [c_int] * 13 + [c_void_p]),
+    "gan_conv2d_wgrad_workspace": (c_int64, [c_int] * 13),
+    "gan_conv2d_wgrad": (c_int, [c_void_p] * 4 + [c_int] * 12 + [c_void_p, c_int64, c_int, c_void_p]),
     "gan_mbstd_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_int, c_void_p]),
     "gan_ema_lerp": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_void_p]),
 }

@@ -100,8 +100,15 @@ int gan_conv2d_fwd_thin(const void* x, const void* wt, void* y, const float* in_
 
 // conv_thin_wgrad.hip: weight gradient for thin layers (bf16); dw must be zeroed by the caller.
 int gan_conv2d_wgrad_thin(const void* x, const void* gy, float* dw, const float* in_scale, int N, int H, int W,
-                          int Cin, int up2, int Ho, int Wo, int Cout, int kh, int kw, int py, int px,
-                          hipStream_t st);
+                          int Cin, int up2, int Ho, int Wo, int Cout, int kh, int kw, int py, int px, float* ws,
+                          int64_t ws_floats, int64_t* need, hipStream_t st);
+// conv_wgrad_tiled.hip: weight gradient for wide layers / small maps (bf16, needs a workspace) and the
+// slice reducer out[e] += sum_s ws[s][e].
+int64_t gan_wgrad_tiled_workspace(int N, int Ho, int Wo, int Cin, int Cout, int kh, int kw, int py, int px);
+int gan_conv2d_wgrad_tiled(const void* x, const void* gy, float* dw, const float* in_scale, int N, int H, int W,
+                           int Cin, int up2, int Ho, int Wo, int Cout, int kh, int kw, int py, int px, float* ws,
+                           int64_t ws_floats, hipStream_t st);
+int gan_reduce_slices(const float* ws, float* out, int64_t L, int S, hipStream_t st);
 
 // upfirdn_mfma.hip: bf16 upfirdn2d with the FIR as banded matrix products on MFMA.  1 / 0 / < 0 as above.
 int gan_upfirdn2d_mfma(const void* x, const float* taps, void* y, int N, int H, int W, int C, int ky, int kx, int up,

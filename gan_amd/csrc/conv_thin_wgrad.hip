@@ -26,6 +26,7 @@ struct ThinWArgs {
     const float* in_scale;
     int N, H, W, Hl, Wl, up2, Ho, Wo, Cin, Cout, py, px;
     int tiles_x, tiles_y;
+    float* ws;  // optional [gridDim.x * WR][taps][Cout][Cin] partial slices (plain stores) instead of atomics
 };
 
 __device__ __forceinline__ uint4 wmod_chunk(uint4 raw, const float* s) {
@@ -159,12 +160,16 @@ __global__ void __launch_bounds__(256) conv_thin_wgrad_k(const ThinWArgs p) {
     }
 
     // ---- flush: D layout col = lane & 15 -> ci, row = 4*(lane >> 4) + r -> co ----------------------
+    // With a workspace every (workgroup, row group) writes its partial sums with plain stores into its own
+    // slice (reduce_slices_k folds them); without one, one fp32 atomic per element into dw.
     if (t0 < t1) {
+        const int64_t L = (int64_t)KS * KS * p.Cout * p.Cin;
+        float* __restrict__ base = p.ws ? p.ws + ((int64_t)blockIdx.x * C::WR + wr) * L : p.dw;
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const int tap = wt + j * WT;
             if (tap >= KS * KS) continue;
-            float* __restrict__ dwt = p.dw + (int64_t)tap * p.Cout * p.Cin;
+            float* __restrict__ dwt = base + (int64_t)tap * p.Cout * p.Cin;
 #pragma unroll
             for (int o = 0; o < CGO; ++o)
 #pragma unroll
@@ -173,14 +178,20 @@ __global__ void __launch_bounds__(256) conv_thin_wgrad_k(const ThinWArgs p) {
                     for (int r = 0; r < 4; ++r) {
                         const int co = o * 16 + g * 4 + r;
                         const int ci = i * 16 + li;
-                        if (co < p.Cout && ci < p.Cin) atomicAdd(dwt + (int64_t)co * p.Cin + ci, acc[j][o][i][r]);
+                        if (co < p.Cout && ci < p.Cin) {
+                            if (p.ws)
+                                dwt[(int64_t)co * p.Cin + ci] = acc[j][o][i][r];
+                            else
+                                atomicAdd(dwt + (int64_t)co * p.Cin + ci, acc[j][o][i][r]);
+                        }
                     }
         }
     }
 }
 
+// `need` != nullptr: only report the workspace (floats) this configuration would use.
 template <int CIN, int COUT, int KS, int TH, int WT>
-int launch_thin_w(ThinWArgs a, hipStream_t st) {
+int launch_thin_w(ThinWArgs a, int64_t ws_floats, int64_t* need, hipStream_t st) {
     typedef ThinWCfg<CIN, COUT, KS, TH, WT> C;
     static_assert(C::LDS_BYTES <= 160 * 1024, "tile does not fit LDS");
     static_assert(TH % C::WR == 0, "rows must split evenly over the row groups");
@@ -192,33 +203,44 @@ int launch_thin_w(ThinWArgs a, hipStream_t st) {
     if (per_cu < 1) per_cu = 1;
     int64_t grid = 256LL * per_cu;
     if (grid > ntiles) grid = ntiles;
+    const int64_t L = (int64_t)KS * KS * a.Cout * a.Cin;
+    const int64_t want = grid * C::WR * L;
+    if (need) {
+        *need = want;
+        return GAN_OK;
+    }
+    const bool use_ws = a.ws != nullptr && ws_floats >= want && (L & 3) == 0;
+    if (!use_ws) a.ws = nullptr;
     hipLaunchKernelGGL((conv_thin_wgrad_k<CIN, COUT, KS, TH, WT>), dim3((unsigned)grid), dim3(256), 0, st, a);
     GAN_CHECK_LAUNCH("conv2d_wgrad(thin)");
+    if (use_ws) return gan_reduce_slices(a.ws, a.dw, L, (int)(grid * C::WR), st);
     return GAN_OK;
 }
 
 template <int CIN, int COUT>
-int pick_ks(const ThinWArgs& a, int ks, hipStream_t st) {
+int pick_ks(const ThinWArgs& a, int ks, int64_t wsf, int64_t* need, hipStream_t st) {
     constexpr int F = (CIN / 16) * (COUT / 16);
     constexpr int TH = (CIN <= 16 && COUT <= 32) ? 16 : 8;
-    if (ks == 1) return launch_thin_w<CIN, COUT, 1, TH, 1>(a, st);
+    if (ks == 1) return launch_thin_w<CIN, COUT, 1, TH, 1>(a, wsf, need, st);
     constexpr int WT = F <= 4 ? 1 : (F <= 8 ? 2 : 4);
-    return launch_thin_w<CIN, COUT, 3, TH, WT>(a, st);
+    return launch_thin_w<CIN, COUT, 3, TH, WT>(a, wsf, need, st);
 }
 
 template <int CIN>
-int pick_cout_w(const ThinWArgs& a, int ks, hipStream_t st) {
-    if (a.Cout <= 16) return pick_ks<CIN, 16>(a, ks, st);
-    if (a.Cout <= 32) return pick_ks<CIN, 32>(a, ks, st);
-    return pick_ks<CIN, 64>(a, ks, st);
+int pick_cout_w(const ThinWArgs& a, int ks, int64_t wsf, int64_t* need, hipStream_t st) {
+    if (a.Cout <= 16) return pick_ks<CIN, 16>(a, ks, wsf, need, st);
+    if (a.Cout <= 32) return pick_ks<CIN, 32>(a, ks, wsf, need, st);
+    return pick_ks<CIN, 64>(a, ks, wsf, need, st);
 }
 
 }  // namespace
 
 // 1 = served (dw must already be zeroed), 0 = shape not eligible, < 0 = error.
+// need != nullptr: query only -- *need = workspace floats the launch would like (0 if not eligible).
 int gan_conv2d_wgrad_thin(const void* x, const void* gy, float* dw, const float* in_scale, int N, int H, int W,
-                          int Cin, int up2, int Ho, int Wo, int Cout, int kh, int kw, int py, int px,
-                          hipStream_t st) {
+                          int Cin, int up2, int Ho, int Wo, int Cout, int kh, int kw, int py, int px, float* ws,
+                          int64_t ws_floats, int64_t* need, hipStream_t st) {
+    if (need) *need = 0;
     if (kh != kw || (kh != 1 && kh != 3)) return 0;
     if (py != (kh - 1) / 2 || px != py) return 0;
     if (Cin > 64 || Cout > 64 || (Cin & 7) || (Cout & 7) || Wo < 32 || Ho < 8) return 0;
@@ -227,9 +249,10 @@ int gan_conv2d_wgrad_thin(const void* x, const void* gy, float* dw, const float*
     a.N = N; a.H = H; a.W = W; a.Hl = up2 ? 2 * H : H; a.Wl = up2 ? 2 * W : W; a.up2 = up2;
     a.Ho = Ho; a.Wo = Wo; a.Cin = Cin; a.Cout = Cout; a.py = py; a.px = px;
     a.tiles_x = a.tiles_y = 0;
+    a.ws = (ws && (((uintptr_t)ws) & 15) == 0) ? ws : nullptr;
     int rc;
-    if (Cin <= 16) rc = pick_cout_w<16>(a, kh, st);
-    else if (Cin <= 32) rc = pick_cout_w<32>(a, kh, st);
-    else rc = pick_cout_w<64>(a, kh, st);
+    if (Cin <= 16) rc = pick_cout_w<16>(a, kh, ws_floats, need, st);
+    else if (Cin <= 32) rc = pick_cout_w<32>(a, kh, ws_floats, need, st);
+    else rc = pick_cout_w<64>(a, kh, ws_floats, need, st);
     return rc == GAN_OK ? 1 : rc;
 }

@@ -234,9 +234,19 @@ int launch(const WgradArgs& a, hipStream_t st) {
 
 }  // namespace
 
+extern "C" int64_t gan_conv2d_wgrad_workspace(int N, int H, int W, int Cin, int up2, int Ho, int Wo, int Cout, int kh,
+                                              int kw, int py, int px, int dtype) {
+    if (dtype != GAN_BF16 || N <= 0) return 0;
+    int64_t need = 0;
+    gan_conv2d_wgrad_thin(nullptr, nullptr, nullptr, nullptr, N, H, W, Cin, up2, Ho, Wo, Cout, kh, kw, py, px, nullptr, 0,
+                          &need, nullptr);
+    if (need > 0) return need;
+    return gan_wgrad_tiled_workspace(N, Ho, Wo, Cin, Cout, kh, kw, py, px);
+}
+
 extern "C" int gan_conv2d_wgrad(const void* x, const void* gy, float* dw, const float* in_scale, int N, int H, int W,
-                                int Cin, int up2, int Ho, int Wo, int Cout, int kh, int kw, int py, int px, int dtype,
-                                gan_stream_t stream) {
+                                int Cin, int up2, int Ho, int Wo, int Cout, int kh, int kw, int py, int px,
+                                float* workspace, int64_t workspace_floats, int dtype, gan_stream_t stream) {
     GAN_CHECK_ARG(dw && (N == 0 || (x && gy)), "conv2d_wgrad: null pointer");
     GAN_CHECK_ARG(dtype == GAN_F32 || dtype == GAN_BF16, "conv2d_wgrad: bad dtype %d", dtype);
     GAN_CHECK_ARG(N >= 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Ho > 0 && Wo > 0, "conv2d_wgrad: bad shape");
@@ -244,6 +254,7 @@ extern "C" int gan_conv2d_wgrad(const void* x, const void* gy, float* dw, const 
                   Cin, Cout);
     GAN_CHECK_ARG(kh >= 1 && kw >= 1 && kh * kw <= 64, "conv2d_wgrad: bad kernel %dx%d", kh, kw);
     GAN_CHECK_ARG(up2 == 0 || up2 == 1, "conv2d_wgrad: up2 must be 0 or 1");
+    GAN_CHECK_ARG(workspace_floats >= 0 && (workspace != nullptr || workspace_floats == 0), "conv2d_wgrad: bad workspace");
     const int Hl = up2 ? 2 * H : H, Wl = up2 ? 2 * W : W;
     GAN_CHECK_ARG(Ho == Hl + 2 * py - kh + 1 && Wo == Wl + 2 * px - kw + 1,
                   "conv2d_wgrad: output %dx%d does not match input %dx%d, kernel %dx%d, pad %d,%d", Ho, Wo, Hl, Wl,
@@ -256,6 +267,14 @@ extern "C" int gan_conv2d_wgrad(const void* x, const void* gy, float* dw, const 
         return GAN_ERR_LAUNCH;
     }
     if (N == 0) return GAN_OK;
+    if (dtype == GAN_BF16) {
+        int rc = gan_conv2d_wgrad_thin(x, gy, dw, in_scale, N, H, W, Cin, up2, Ho, Wo, Cout, kh, kw, py, px, workspace,
+                                       workspace_floats, nullptr, st);
+        if (rc != 0) return rc < 0 ? rc : GAN_OK;
+        rc = gan_conv2d_wgrad_tiled(x, gy, dw, in_scale, N, H, W, Cin, up2, Ho, Wo, Cout, kh, kw, py, px, workspace,
+                                    workspace_floats, st);
+        if (rc != 0) return rc < 0 ? rc : GAN_OK;
+    }
     WgradArgs a;
     a.x = x; a.gy = gy; a.dw = dw; a.in_scale = in_scale;
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Hl = Hl; a.Wl = Wl; a.up2 = up2;
@@ -264,7 +283,5 @@ extern "C" int gan_conv2d_wgrad(const void* x, const void* gy, float* dw, const 
     a.M = (int64_t)N * Ho * Wo;
     a.pix_per_split = 128;
     if (dtype == GAN_F32) return launch<float>(a, st);
-    const int thin = gan_conv2d_wgrad_thin(x, gy, dw, in_scale, N, H, W, Cin, up2, Ho, Wo, Cout, kh, kw, py, px, st);
-    if (thin != 0) return thin < 0 ? thin : GAN_OK;
     return launch<bf16>(a, st);
 }

@@ -1,0 +1,340 @@
+// Weight gradient for WIDE layers / small feature maps on MFMA (gfx950), bf16, plus the slice reducer
+// shared with conv_thin_wgrad.hip.
+//
+//   dw[tap][co][ci] = sum_{n,oy,ox} gy[n,oy,ox,co] * X[n, oy+dy-py, ox+dx-px, ci] * in_scale[n][ci]
+//
+// Same idea as the thin kernel -- stage a block of pixels ONCE in LDS and form every tap from that
+// image -- organised for 128..512 channels on 4x4..64x64 maps:
+//   * a workgroup (3 waves) owns a 64 x 64 (co x ci) channel tile and a contiguous range of 128-pixel
+//     spatial tiles: TH x 32 rows of one image, half / whole 16 x 16 images, 2 images of 8 x 8, 8 of 4 x 4;
+//   * wave w owns kernel row dy = w: 3 taps x 16 fragment accumulators (192 registers) that live
+//     across all tiles of the workgroup (1x1 convolutions: the waves split the K steps instead);
+//   * k = 32 consecutive tile-linear pixels per MFMA; both operands are pixel-major, stored as
+//     [16-channel group][pixel][16 ch] and read with ds_read_b64_tr_b16 (per-lane halo offsets);
+//   * split-K over pixel tiles: every workgroup writes its partial tile with plain stores into slice
+//     s of a caller-provided workspace [S][taps][Cout][Cin]; reduce_slices_k folds the slices.
+//     (fp32 atomics from ~500 workgroups into one 147 KB tile ran at 0.3 TB/s and dominated.)
+#include "common.h"
+
+namespace {
+
+struct TWArgs {
+    const void* x;
+    const void* gy;
+    float* ws;
+    const float* in_scale;
+    int N, H, W, Hl, Wl, up2, Ho, Wo, Cin, Cout, py, px;
+    int tiles_x, tiles_y;           // per image (NB == 1)
+    int ntiles, S, ci_tiles;
+};
+
+__device__ __forceinline__ uint4 tmod_chunk(uint4 raw, const float* s) {
+    bf16x8 v = *reinterpret_cast<bf16x8*>(&raw);
+    const float4 s0 = *reinterpret_cast<const float4*>(s);
+    const float4 s1 = *reinterpret_cast<const float4*>(s + 4);
+    v[0] = (bf16)((float)v[0] * s0.x);
+    v[1] = (bf16)((float)v[1] * s0.y);
+    v[2] = (bf16)((float)v[2] * s0.z);
+    v[3] = (bf16)((float)v[3] * s0.w);
+    v[4] = (bf16)((float)v[4] * s1.x);
+    v[5] = (bf16)((float)v[5] * s1.y);
+    v[6] = (bf16)((float)v[6] * s1.z);
+    v[7] = (bf16)((float)v[7] * s1.w);
+    return *reinterpret_cast<uint4*>(&v);
+}
+
+__device__ __forceinline__ bf16x8 tr_frag2(const char* plo, const char* phi) {
+    typedef bf16x4 __attribute__((address_space(3))) * lds_ptr;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_ptr)plo);
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_ptr)phi);
+    bf16x8 f;
+    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+    f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+    return f;
+}
+
+constexpr int TW_LOADERS = 2;  // producer waves (waves 3, 4); waves 0-2 are MFMA consumers
+constexpr int TW_U = 13;       // 16-byte loads a producer lane keeps in flight per batch
+
+// Tile geometry is a template parameter: the producers turn a chunk index into (image, row, column) with
+// divisions by HALO and HWD for every 16-byte load, which as run-time divisions made them VALU-bound
+// (PMC: consumers waited 67 % of their cycles on the stage barrier).
+template <int KS, int TWL, int THL, int NBL>
+__global__ void __launch_bounds__(320) conv_wgrad_tiled_k(const TWArgs p) {
+    extern __shared__ __attribute__((aligned(256))) char tw_lds[];
+    constexpr int NT = KS;  // taps (dx) per consumer wave
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
+    constexpr int TW = 1 << TWL, TH = 1 << THL, NB = 1 << NBL;
+    constexpr int HWD = TW + KS - 1, HALO = HWD * (TH + KS - 1), NPX = NB * HALO;
+    constexpr int PLX = NPX * 32, PLG = 128 * 32;
+    constexpr int BUF = 4 * PLX + 4 * PLG;  // one stage: x planes, then gy planes
+    const int co0 = (blockIdx.x / p.ci_tiles) * 64, ci0 = (blockIdx.x % p.ci_tiles) * 64;
+    const int s = blockIdx.y;
+    const int t0 = (int)((int64_t)p.ntiles * s / p.S), t1 = (int)((int64_t)p.ntiles * (s + 1) / p.S);
+    constexpr int thw_log2 = THL + TWL;
+    const int tiles_per_img = p.tiles_x * p.tiles_y;
+
+    f32x4 acc[NT][4][4];
+
+    if (wave >= 3) {
+        // ================= producers: tile t -> LDS stage (t - t0) & 1, TW_U loads in flight per lane ====
+        const bf16* __restrict__ x = (const bf16*)p.x;
+        const bf16* __restrict__ gy = (const bf16*)p.gy;
+        const int ltid = tid - 192;
+        constexpr int nxc = ((NPX + 7) >> 3) * 64;  // x chunks (8 pixels x 8 channel chunks per 64)
+        constexpr int ntot = nxc + 128 * 8;         // + gy chunks
+        for (int t = t0; t < t1; ++t) {
+            char* const xl = tw_lds + ((t - t0) & 1) * BUF;
+            char* const gl = xl + 4 * PLX;
+            int n0, oy0, ox0;
+            if (NB == 1) {
+                n0 = t / tiles_per_img;
+                const int rem = t - n0 * tiles_per_img;
+                const int ty = rem / p.tiles_x;
+                oy0 = ty * TH;
+                ox0 = (rem - ty * p.tiles_x) * TW;
+            } else {
+                n0 = t * NB;
+                oy0 = ox0 = 0;
+            }
+            for (int base = 0; base < ntot; base += TW_U * 64 * TW_LOADERS) {
+                uint4 v[TW_U];
+                int dst[TW_U], sc[TW_U];
+#pragma unroll
+                for (int k = 0; k < TW_U; ++k) {
+                    const int idx = base + k * 64 * TW_LOADERS + ltid;
+                    v[k] = make_uint4(0, 0, 0, 0);
+                    dst[k] = -1;
+                    sc[k] = -1;
+                    if (idx < nxc) {
+                        const int c8 = (idx >> 3) & 7;
+                        const int pix = (idx >> 6) * 8 + (idx & 7);
+                        if (pix < NPX) {
+                            const int b = pix / HALO, r = pix - b * HALO;
+                            const int hy = r / HWD, hx = r - hy * HWD;
+                            const int n = n0 + b, ly = oy0 - p.py + hy, lx = ox0 - p.px + hx;
+                            const int ci = ci0 + c8 * 8;
+                            dst[k] = (c8 >> 1) * PLX + pix * 32 + (c8 & 1) * 16;
+                            if (n < p.N && (unsigned)ly < (unsigned)p.Hl && (unsigned)lx < (unsigned)p.Wl && ci < p.Cin) {
+                                v[k] = *reinterpret_cast<const uint4*>(x + (((int64_t)n * p.H + (ly >> p.up2)) * p.W + (lx >> p.up2)) * p.Cin + ci);
+                                if (p.in_scale) sc[k] = n * p.Cin + ci;
+                            }
+                        }
+                    } else if (idx < ntot) {
+                        const int j = idx - nxc;
+                        const int c8 = (j >> 3) & 7;
+                        const int P = (j >> 6) * 8 + (j & 7);
+                        const int b = P >> thw_log2;
+                        const int oy = oy0 + ((P >> TWL) & (TH - 1)), ox = ox0 + (P & (TW - 1));
+                        const int n = n0 + b, co = co0 + c8 * 8;
+                        dst[k] = 4 * PLX + (c8 >> 1) * PLG + P * 32 + (c8 & 1) * 16;
+                        if (n < p.N && oy < p.Ho && ox < p.Wo && co < p.Cout)
+                            v[k] = *reinterpret_cast<const uint4*>(gy + (((int64_t)n * p.Ho + oy) * p.Wo + ox) * p.Cout + co);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < TW_U; ++k) {
+                    if (dst[k] >= 0) {
+                        uint4 u = v[k];
+                        if (sc[k] >= 0) u = tmod_chunk(u, p.in_scale + sc[k]);
+                        *reinterpret_cast<uint4*>(xl + dst[k]) = u;
+                    }
+                }
+            }
+            (void)gl;
+            __syncthreads();  // stage ready; consumers have left the stage this overwrites two tiles later
+        }
+    } else {
+        // ================= consumers: wave = kernel row dy (1x1: the waves split the K steps) ============
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int o = 0; o < 4; ++o)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[j][o][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int t = t0; t < t1; ++t) {
+            __syncthreads();  // tile t is in its stage
+            const char* const xl = tw_lds + ((t - t0) & 1) * BUF;
+            const char* const gl = xl + 4 * PLX;
+#pragma unroll 1
+            for (int ks = 0; ks < 4; ++ks) {
+                if (KS == 1 && (ks % 3) != wave) continue;
+                const int Plo = ks * 32 + 4 * g + q, Phi = Plo + 16;
+                bf16x8 a[4];
+#pragma unroll
+                for (int o = 0; o < 4; ++o) a[o] = tr_frag2(gl + o * PLG + Plo * 32 + pp * 8, gl + o * PLG + Phi * 32 + pp * 8);
+                const int dy = KS == 1 ? 0 : wave;
+                const int hlo = (Plo >> thw_log2) * HALO + (((Plo >> TWL) & (TH - 1)) + dy) * HWD + (Plo & (TW - 1));
+                const int hhi = (Phi >> thw_log2) * HALO + (((Phi >> TWL) & (TH - 1)) + dy) * HWD + (Phi & (TW - 1));
+                const char* const blo = xl + hlo * 32 + pp * 8;
+                const char* const bhi = xl + hhi * 32 + pp * 8;
+#pragma unroll
+                for (int dx = 0; dx < NT; ++dx) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const bf16x8 b = tr_frag2(blo + i * PLX + dx * 32, bhi + i * PLX + dx * 32);
+#pragma unroll
+                        for (int o = 0; o < 4; ++o)
+                            acc[dx][o][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[o], b, acc[dx][o][i], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        // ---- partial tile -> workspace slice s, final layout [tap][Cout][Cin] (3x3: one tap row per wave)
+        if (KS != 1) {
+            float* __restrict__ slice = p.ws + (int64_t)s * KS * KS * p.Cout * p.Cin;
+#pragma unroll
+            for (int dx = 0; dx < NT; ++dx) {
+                float* __restrict__ dst = slice + (int64_t)(wave * KS + dx) * p.Cout * p.Cin;
+#pragma unroll
+                for (int o = 0; o < 4; ++o)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int co = co0 + o * 16 + g * 4 + r, ci = ci0 + i * 16 + li;
+                            if (co < p.Cout && ci < p.Cin) dst[(int64_t)co * p.Cin + ci] = acc[dx][o][i][r];
+                        }
+            }
+        }
+    }
+    if (KS == 1) {
+        // three consumer waves hold partial sums of the same tap: fold them through LDS (all loads landed)
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(tw_lds);
+        if (wave < 3) {
+#pragma unroll
+            for (int o = 0; o < 4; ++o)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) red[wave * 4096 + (o * 16 + g * 4 + r) * 64 + i * 16 + li] = acc[0][o][i][r];
+        }
+        __syncthreads();
+        float* __restrict__ slice = p.ws + (int64_t)s * p.Cout * p.Cin;
+        for (int e = tid; e < 4096; e += 320) {
+            const int co = co0 + (e >> 6), ci = ci0 + (e & 63);
+            if (co < p.Cout && ci < p.Cin) slice[(int64_t)co * p.Cin + ci] = red[e] + red[4096 + e] + red[8192 + e];
+        }
+    }
+}
+
+// out[e] += sum over a chunk of 32 slices of ws[s][e]   (out zeroed by the caller; few adders per address)
+__global__ void __launch_bounds__(256) reduce_slices_k(const float* __restrict__ ws, float* __restrict__ out, int64_t L,
+                                                       int S) {
+    const int64_t e4 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e4 * 4 >= L) return;
+    const int s0 = blockIdx.y * 32;
+    const int s1 = min(S, s0 + 32);
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* __restrict__ src = ws + e4 * 4;
+#pragma unroll 8
+    for (int s = s0; s < s1; ++s) {
+        const float4 v = *reinterpret_cast<const float4*>(src + (int64_t)s * L);
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    float* o = out + e4 * 4;
+    if (gridDim.y == 1) {
+        *reinterpret_cast<float4*>(o) = a;
+    } else {
+        atomicAdd(o, a.x); atomicAdd(o + 1, a.y); atomicAdd(o + 2, a.z); atomicAdd(o + 3, a.w);
+    }
+}
+
+struct TiledPlan {
+    bool ok;
+    int tw_log2, th_log2, nb_log2, tiles_x, tiles_y, ntiles, S, co_tiles, ci_tiles, lds;
+};
+
+TiledPlan plan_tiled(int N, int Ho, int Wo, int Cin, int Cout, int ks) {
+    TiledPlan pl;
+    pl.ok = false;
+    if (Wo >= 32) {
+        pl.tw_log2 = 5; pl.th_log2 = 2; pl.nb_log2 = 0;
+    } else if (Wo == 16 && Ho == 16) {
+        pl.tw_log2 = 4; pl.th_log2 = 3; pl.nb_log2 = 0;
+    } else if (Wo == 8 && Ho == 8) {
+        pl.tw_log2 = 3; pl.th_log2 = 3; pl.nb_log2 = 1;
+    } else if (Wo == 4 && Ho == 4) {
+        pl.tw_log2 = 2; pl.th_log2 = 2; pl.nb_log2 = 3;
+    } else {
+        return pl;
+    }
+    const int TW = 1 << pl.tw_log2, TH = 1 << pl.th_log2, NB = 1 << pl.nb_log2;
+    pl.tiles_x = (Wo + TW - 1) / TW;
+    pl.tiles_y = (Ho + TH - 1) / TH;
+    const int64_t nt = NB == 1 ? (int64_t)N * pl.tiles_x * pl.tiles_y : (N + NB - 1) / NB;
+    if (nt <= 0 || nt >= (1LL << 30)) return pl;
+    pl.ntiles = (int)nt;
+    pl.co_tiles = (Cout + 63) / 64;
+    pl.ci_tiles = (Cin + 63) / 64;
+    const int ct = pl.co_tiles * pl.ci_tiles;
+    int S = (256 + ct - 1) / ct;  // one 5-wave workgroup per CU (two LDS stages, 256-register consumers)
+    if (S > pl.ntiles) S = pl.ntiles;
+    if (S > 65535) S = 65535;
+    pl.S = S;
+    const int NPX = NB * (TW + ks - 1) * (TH + ks - 1);
+    pl.lds = 2 * (4 * NPX * 32 + 4 * 128 * 32);  // two stages
+    if (ks == 1 && pl.lds < 3 * 4096 * 4) pl.lds = 3 * 4096 * 4;
+    pl.ok = true;
+    return pl;
+}
+
+}  // namespace
+
+// floats of workspace gan_conv2d_wgrad_tiled needs for this shape (0: shape not served by it)
+int64_t gan_wgrad_tiled_workspace(int N, int Ho, int Wo, int Cin, int Cout, int kh, int kw, int py, int px) {
+    if (kh != kw || (kh != 1 && kh != 3) || py != (kh - 1) / 2 || px != py) return 0;
+    if ((Cin & 7) || (Cout & 7)) return 0;
+    const TiledPlan pl = plan_tiled(N, Ho, Wo, Cin, Cout, kh);
+    if (!pl.ok) return 0;
+    return (int64_t)pl.S * kh * kw * Cout * Cin;
+}
+
+// 1 = served (dw zeroed by the caller), 0 = not eligible / workspace too small, < 0 = error.
+int gan_conv2d_wgrad_tiled(const void* x, const void* gy, float* dw, const float* in_scale, int N, int H, int W,
+                           int Cin, int up2, int Ho, int Wo, int Cout, int kh, int kw, int py, int px, float* ws,
+                           int64_t ws_floats, hipStream_t st) {
+    const int64_t need = gan_wgrad_tiled_workspace(N, Ho, Wo, Cin, Cout, kh, kw, py, px);
+    if (need == 0 || ws == nullptr || ws_floats < need || (((uintptr_t)ws) & 15)) return 0;
+    const TiledPlan pl = plan_tiled(N, Ho, Wo, Cin, Cout, kh);
+    TWArgs a;
+    a.x = x; a.gy = gy; a.ws = ws; a.in_scale = in_scale;
+    a.N = N; a.H = H; a.W = W; a.Hl = up2 ? 2 * H : H; a.Wl = up2 ? 2 * W : W; a.up2 = up2;
+    a.Ho = Ho; a.Wo = Wo; a.Cin = Cin; a.Cout = Cout; a.py = py; a.px = px;
+    a.tiles_x = pl.tiles_x; a.tiles_y = pl.tiles_y; a.ntiles = pl.ntiles; a.S = pl.S; a.ci_tiles = pl.ci_tiles;
+    const dim3 grid((unsigned)(pl.co_tiles * pl.ci_tiles), (unsigned)pl.S);
+#define TW_LAUNCH(KS_, TWL_, THL_, NBL_) \
+    hipLaunchKernelGGL((conv_wgrad_tiled_k<KS_, TWL_, THL_, NBL_>), grid, dim3(320), (size_t)pl.lds, st, a)
+    if (kh == 3) {
+        if (pl.tw_log2 == 5) TW_LAUNCH(3, 5, 2, 0);
+        else if (pl.tw_log2 == 4) TW_LAUNCH(3, 4, 3, 0);
+        else if (pl.tw_log2 == 3) TW_LAUNCH(3, 3, 3, 1);
+        else TW_LAUNCH(3, 2, 2, 3);
+    } else {
+        if (pl.tw_log2 == 5) TW_LAUNCH(1, 5, 2, 0);
+        else if (pl.tw_log2 == 4) TW_LAUNCH(1, 4, 3, 0);
+        else if (pl.tw_log2 == 3) TW_LAUNCH(1, 3, 3, 1);
+        else TW_LAUNCH(1, 2, 2, 3);
+    }
+#undef TW_LAUNCH
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        gan_set_error("conv2d_wgrad(tiled): launch failed: %s", hipGetErrorString(e));
+        return GAN_ERR_LAUNCH;
+    }
+    const int rc = gan_reduce_slices(ws, dw, (int64_t)kh * kw * Cout * Cin, pl.S, st);
+    return rc == GAN_OK ? 1 : rc;
+}
+
+int gan_reduce_slices(const float* ws, float* out, int64_t L, int S, hipStream_t st) {
+    const int64_t blocks = ceil_div64(ceil_div64(L, 4), 256);
+    hipLaunchKernelGGL(reduce_slices_k, dim3((unsigned)blocks, (unsigned)((S + 31) / 32)), dim3(256), 0, st, ws, out, L, S);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        gan_set_error("reduce_slices: launch failed: %s", hipGetErrorString(e));
+        return GAN_ERR_LAUNCH;
+    }
+    return GAN_OK;
+}

@@ -25,6 +25,7 @@ struct FirArgs {
     int H, W, C, ky, kx, up_log2, down, px1, py1, Ho, Wo;
     int TH, ncg_log2, KC, RWr, RHmax, tiles_x, tiles_y, xstep, ncols, ncb;
     int64_t ntiles;
+    unsigned rw_magic;  // ceil(2^32 / RWr)
 };
 
 __device__ __forceinline__ bf16x8 fir_tr_frag(const char* p) {
@@ -95,7 +96,7 @@ __global__ void __launch_bounds__(256, 4) upfirdn2d_mfma_k(const FirArgs p) {
             const int c8 = r8 >> 3;
             const int pix = p8 * 8 + (r8 & 7);
             if (pix >= npix) continue;
-            const int ry = pix / p.RWr, rx = pix - ry * p.RWr;
+            const int ry = (int)__umulhi((unsigned)pix, p.rw_magic), rx = pix - ry * p.RWr;  // pix / RWr, exact for pix < 2^16
             const int iy = iy0 + ry, ix = ix0 + rx;
             uint4 v = make_uint4(0, 0, 0, 0);
             if (rx < p.ncols && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
@@ -170,6 +171,7 @@ int gan_upfirdn2d_mfma(const void* x, const float* taps, void* y, int N, int H, 
     a.xstep = 16 * down / up;
     a.RWr = 32 * a.KC + a.xstep;
     a.ncols = a.xstep + kneed + 1;
+    a.rw_magic = (unsigned)((0x100000000ULL + a.RWr - 1) / a.RWr);
     int lds = 0;
     int ncg_log2 = 2;
     for (;; --ncg_log2) {

@@ -334,11 +334,16 @@ def raw_conv2d_wgrad(
         if cin_p != cin:
             in_scale = F.pad(in_scale, (0, cin_p - cin)).contiguous()
     dw = torch.empty((kh * kw, cout_p, cin_p), dtype=torch.float32, device=x.device)
+    # split-K partials go to a caller-owned workspace (the library never allocates); torch's caching
+    # allocator hands the same block back every step
+    ws_floats = lib.gan_conv2d_wgrad_workspace(n, h, w, cin_p, int(up2), ho, wo, cout_p, kh, kw, py, px, dtype_code(x))
+    ws = torch.empty((ws_floats,), dtype=torch.float32, device=x.device) if ws_floats > 0 else None
     check(
         _run(
             "conv2d_wgrad", 2.0 * n * ho * wo * cout * cin * kh * kw, _nbytes(x, gy, dw),
             lambda: lib.gan_conv2d_wgrad(
-                ptr(x), ptr(gy), ptr(dw), ptr(in_scale), n, h, w, cin_p, int(up2), ho, wo, cout_p, kh, kw, py, px, dtype_code(x), stream_of(x)
+                ptr(x), ptr(gy), ptr(dw), ptr(in_scale), n, h, w, cin_p, int(up2), ho, wo, cout_p, kh, kw, py, px,
+                ptr(ws), ws_floats, dtype_code(x), stream_of(x)
             ),
             (n, cin, ho, wo, cout, kh, int(up2)),
         ),

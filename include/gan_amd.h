@@ -98,11 +98,16 @@ int gan_conv2d_fwd(const void* x, const void* wt, void* y, const float* in_scale
 
 /* Weight gradient (autograd of the convolutions above):
  * dw[tap][co][ci] = sum_{n,oy,ox} gy[n,oy,ox,co] * X[n,oy+dy-py,ox+dx-px,ci] * in_scale[n,ci]
- * dw: fp32 [kh*kw][Cout][Cin], zeroed here, accumulated with fp32 atomics over pixel splits.
- * Cin % 16 == 0 and Cout % 16 == 0 (callers pad). */
+ * dw: fp32 [kh*kw][Cout][Cin], zeroed here.  Cin % 16 == 0 and Cout % 16 == 0 (callers pad).
+ * The reduction over pixels is split over workgroups; with a workspace of at least
+ * gan_conv2d_wgrad_workspace(...) floats (16-byte aligned, contents undefined on entry and exit) the
+ * partial tiles are written with plain stores and folded by a second kernel, otherwise (workspace NULL)
+ * they are accumulated into dw with fp32 atomics.  The library never allocates: the caller owns it. */
+int64_t gan_conv2d_wgrad_workspace(int N, int H, int W, int Cin, int up2, int Ho, int Wo, int Cout, int kh, int kw,
+                                   int py, int px, int dtype);
 int gan_conv2d_wgrad(const void* x, const void* gy, float* dw, const float* in_scale, int N, int H, int W, int Cin,
-                     int up2, int Ho, int Wo, int Cout, int kh, int kw, int py, int px, int dtype,
-                     gan_stream_t stream);
+                     int up2, int Ho, int Wo, int Cout, int kh, int kw, int py, int px, float* workspace,
+                     int64_t workspace_floats, int dtype, gan_stream_t stream);
 
 /* ---- MinibatchStdDev ---------------------------------------------------------------------
  * replaces MinibatchStdDev.forward   modelling/progressive_gan.py:20-36

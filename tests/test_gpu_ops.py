@@ -365,3 +365,40 @@ def test_conv2d_thin_wgrad_kernel(dev, case):
     ref2 = torch.nn.grad.conv2d_weight(x.double(), (cout, cin, k, k), gy[:, :, :h, :w].double(), padding=pad)
     got2 = GF.raw_conv2d_wgrad(x.to(dev), gy[:, :, :h, :w].contiguous().to(dev), k, k, pad, pad)
     assert rel_err(got2, ref2) < 1e-4, rel_err(got2, ref2)
+
+
+TILED_WGRAD_CASES = [
+    # N, Cin, H, W, Cout, k, up2   (bf16; wide channels or small maps: conv_wgrad_tiled.hip)
+    (4, 128, 32, 32, 256, 3, False),
+    (8, 512, 8, 8, 512, 3, False),
+    (5, 256, 8, 8, 128, 3, False),  # odd batch: the last 2-image tile is half empty
+    (6, 256, 16, 16, 128, 3, False),
+    (3, 256, 8, 8, 128, 3, True),  # 8x8 -> 16x16 nearest-up fused into the staging
+    (16, 520, 4, 4, 512, 3, False),  # MinibatchStdDev layer (513 channels, padded)
+    (19, 128, 4, 4, 80, 3, False),
+    (4, 128, 32, 32, 256, 1, False),  # D shortcut 1x1
+    (8, 256, 16, 16, 512, 1, False),
+    (3, 80, 35, 41, 72, 3, False),  # ragged tiles, channel tiles with tails
+    (2, 64, 64, 64, 128, 3, False),
+    (2, 128, 32, 32, 64, 3, True),
+]
+
+
+@pytest.mark.parametrize("case", TILED_WGRAD_CASES)
+def test_conv2d_tiled_wgrad_kernel(dev, case):
+    import gan_amd.functional as GF
+    from oracle import gan_oracle as O
+
+    n, cin, h, w, cout, k, up2 = case
+    torch.manual_seed(13)
+    pad = (k - 1) // 2
+    x = torch.randn(n, cin, h, w).bfloat16()
+    s = torch.randn(n, cin) * 0.5 + 1
+    ho, wo = (2 * h, 2 * w) if up2 else (h, w)
+    gy = torch.randn(n, cout, ho, wo).bfloat16()
+    xl = O.nearest_up2(x.double()) if up2 else x.double()
+    xs = (xl * s.double().view(n, cin, 1, 1)).bfloat16().double()
+    ref = torch.nn.grad.conv2d_weight(xs, (cout, cin, k, k), gy.double(), padding=pad)
+    got = GF.raw_conv2d_wgrad(x.to(dev), gy.to(dev), k, k, pad, pad, up2=up2, in_scale=s.to(dev))
+    assert got.shape == ref.shape and got.dtype == torch.float32
+    assert rel_err(got, ref) < 1e-4, rel_err(got, ref)

@@ -1,0 +1,26 @@
+"""Micro-driver for one library op (profiling aid): python tools/bench_op.py wgrad N Cin H W Cout k [iters]"""
+import sys, torch
+sys.path.insert(0, '.')
+import gan_amd.functional as GF
+op = sys.argv[1]
+n, cin, h, w, cout, k = map(int, sys.argv[2:8])
+iters = int(sys.argv[8]) if len(sys.argv) > 8 else 10
+dev = torch.device('cuda:0')
+x = torch.randn(n, cin, h, w, device=dev).bfloat16().contiguous(memory_format=torch.channels_last)
+gy = torch.randn(n, cout, h, w, device=dev).bfloat16().contiguous(memory_format=torch.channels_last)
+wgt = torch.randn(cout, cin, k, k, device=dev) / (cin * k * k) ** 0.5
+pad = (k - 1) // 2
+def run():
+    if op == 'wgrad':
+        return GF.raw_conv2d_wgrad(x, gy, k, k, pad, pad)
+    if op == 'fwd':
+        return GF.raw_conv2d(x, wgt, pad, pad)
+    raise SystemExit(op)
+for _ in range(3): run()
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(iters): run()
+e1.record(); torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / iters
+print(f"{op} {n}x{cin}x{h}x{w}->{cout} k{k}: {ms*1e3:.1f} us  {2.0*n*h*w*cout*cin*k*k/ms/1e9:.1f} TFLOP/s")
