@@ -14,7 +14,8 @@ import torch
 from torch import Tensor
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgan_amd.so")
+# GAN_AMD_LIB: development aid (A/B builds of the same ABI); the product loads the in-tree library
+LIB_PATH = os.environ.get("GAN_AMD_LIB") or os.path.join(_HERE, "libgan_amd.so")
 
 GAN_F32, GAN_BF16 = 0, 1
 ABI_VERSION = 2

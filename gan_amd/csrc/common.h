@@ -89,6 +89,15 @@ __device__ __forceinline__ void store_f<bf16, 1>(bf16* p, const float (&in)[1]) 
     *p = (bf16)in[0];
 }
 
+// 16-byte global load that is ALWAYS issued (invalid lanes read the buffer's first bytes and get zeros by
+// a select afterwards).  A load inside `if (ok)` makes hipcc branch around it and wait for each one in
+// turn, which serialises a batch of staging loads into that many memory latencies (measured: the wide
+// weight-gradient producers waited 68 % of their cycles that way).
+__device__ __forceinline__ uint4 ld16_or_zero(const void* base, int64_t elem_off_bytes, bool ok) {
+    const uint4 v = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(base) + (ok ? elem_off_bytes : 0));
+    return ok ? v : make_uint4(0u, 0u, 0u, 0u);
+}
+
 __device__ __forceinline__ float lrelu_f(float v, float slope) { return v > 0.f ? v : v * slope; }
 __device__ __forceinline__ float lrelu_mask(float y, float slope) { return y > 0.f ? 1.f : slope; }
 

@@ -54,12 +54,12 @@ __device__ __forceinline__ bf16x8 tr_frag2(const char* plo, const char* phi) {
 }
 
 constexpr int TW_LOADERS = 2;  // producer waves (waves 3, 4); waves 0-2 are MFMA consumers
-constexpr int TW_U = 13;       // 16-byte loads a producer lane keeps in flight per batch
+
 
 // Tile geometry is a template parameter: the producers turn a chunk index into (image, row, column) with
 // divisions by HALO and HWD for every 16-byte load, which as run-time divisions made them VALU-bound
 // (PMC: consumers waited 67 % of their cycles on the stage barrier).
-template <int KS, int TWL, int THL, int NBL>
+template <int KS, int TWL, int THL, int NBL, bool MOD>
 __global__ void __launch_bounds__(320) conv_wgrad_tiled_k(const TWArgs p) {
     extern __shared__ __attribute__((aligned(256))) char tw_lds[];
     constexpr int NT = KS;  // taps (dx) per consumer wave
@@ -84,9 +84,44 @@ __global__ void __launch_bounds__(320) conv_wgrad_tiled_k(const TWArgs p) {
         const int ltid = tid - 192;
         constexpr int nxc = ((NPX + 7) >> 3) * 64;  // x chunks (8 pixels x 8 channel chunks per 64)
         constexpr int ntot = nxc + 128 * 8;         // + gy chunks
+        // Branch-free, division-free staging.  Chunk slot `sl` of this lane (idx = sl * 128 + ltid) always
+        // maps to the same (x | gy, image b, row, col, channel chunk) of a tile, so that decode is done ONCE
+        // here and kept packed in a register per slot; per tile a slot costs ~20 VALU ops, one unconditional
+        // 16-byte load (ld16_or_zero) and one unconditional LDS store (chunks past the image go to a per-lane
+        // dump slot behind the two stages).  History: with `if`s around the loads hipcc emitted a branch and a
+        // vmcnt wait per load, and with run-time divisions ~115 VALU ops per load; either way the producers took
+        // 3x as long as the consumers' MFMAs (ablation: 299 us loads only vs 104 us MFMAs only).
+        constexpr int NSLOT = (ntot + 64 * TW_LOADERS - 1) / (64 * TW_LOADERS);
+        constexpr int U = MOD ? 7 : 14;  // loads in flight per lane and batch
+        int packed[NSLOT], dsto[NSLOT];
+        const int c8l = (ltid >> 3) & 7;  // channel chunk: the same for every slot of a lane
+#pragma unroll
+        for (int sl = 0; sl < NSLOT; ++sl) {
+            const int idx = sl * 64 * TW_LOADERS + ltid;
+            const bool isx = idx < nxc;
+            const int j = isx ? idx : idx - nxc;
+            const int pix = (j >> 6) * 8 + (j & 7);
+            int bb, yy, xx, okc, d;
+            if (isx) {
+                bb = pix / HALO;
+                const int r = pix - bb * HALO;
+                yy = r / HWD;
+                xx = r - yy * HWD;
+                okc = pix < NPX && ci0 + c8l * 8 < p.Cin;
+                d = pix < NPX ? (c8l >> 1) * PLX + pix * 32 + (c8l & 1) * 16 : -1;
+            } else {
+                bb = pix >> thw_log2;
+                yy = (pix >> TWL) & (TH - 1);
+                xx = pix & (TW - 1);
+                okc = idx < ntot && co0 + c8l * 8 < p.Cout;
+                d = idx < ntot ? 4 * PLX + (c8l >> 1) * PLG + pix * 32 + (c8l & 1) * 16 : -1;
+            }
+            packed[sl] = yy | (xx << 8) | (bb << 16) | ((isx ? 1 : 0) << 24) | (okc << 25);
+            dsto[sl] = d;
+        }
+        const int cix = ci0 + c8l * 8, cog = co0 + c8l * 8;
         for (int t = t0; t < t1; ++t) {
             char* const xl = tw_lds + ((t - t0) & 1) * BUF;
-            char* const gl = xl + 4 * PLX;
             int n0, oy0, ox0;
             if (NB == 1) {
                 n0 = t / tiles_per_img;
@@ -98,51 +133,52 @@ __global__ void __launch_bounds__(320) conv_wgrad_tiled_k(const TWArgs p) {
                 n0 = t * NB;
                 oy0 = ox0 = 0;
             }
-            for (int base = 0; base < ntot; base += TW_U * 64 * TW_LOADERS) {
-                uint4 v[TW_U];
-                int dst[TW_U], sc[TW_U];
+            const int dump = 2 * BUF + ltid * 16 - ((t - t0) & 1) * BUF;
 #pragma unroll
-                for (int k = 0; k < TW_U; ++k) {
-                    const int idx = base + k * 64 * TW_LOADERS + ltid;
-                    v[k] = make_uint4(0, 0, 0, 0);
-                    dst[k] = -1;
-                    sc[k] = -1;
-                    if (idx < nxc) {
-                        const int c8 = (idx >> 3) & 7;
-                        const int pix = (idx >> 6) * 8 + (idx & 7);
-                        if (pix < NPX) {
-                            const int b = pix / HALO, r = pix - b * HALO;
-                            const int hy = r / HWD, hx = r - hy * HWD;
-                            const int n = n0 + b, ly = oy0 - p.py + hy, lx = ox0 - p.px + hx;
-                            const int ci = ci0 + c8 * 8;
-                            dst[k] = (c8 >> 1) * PLX + pix * 32 + (c8 & 1) * 16;
-                            if (n < p.N && (unsigned)ly < (unsigned)p.Hl && (unsigned)lx < (unsigned)p.Wl && ci < p.Cin) {
-                                v[k] = *reinterpret_cast<const uint4*>(x + (((int64_t)n * p.H + (ly >> p.up2)) * p.W + (lx >> p.up2)) * p.Cin + ci);
-                                if (p.in_scale) sc[k] = n * p.Cin + ci;
-                            }
+            for (int b0 = 0; b0 < NSLOT; b0 += U) {
+                uint4 v[U];
+                float4 s0[MOD ? U : 1], s1[MOD ? U : 1];
+#pragma unroll
+                for (int k = 0; k < U; ++k) {
+                    if (b0 + k < NSLOT) {
+                        const int pk = packed[b0 + k];
+                        const bool isx = (pk >> 24) & 1;
+                        const int nn = n0 + ((pk >> 16) & 0xff);
+                        const int y = (isx ? oy0 - p.py : oy0) + (pk & 0xff);
+                        const int xq = (isx ? ox0 - p.px : ox0) + ((pk >> 8) & 0xff);
+                        const bool ok = ((pk >> 25) & 1) && nn < p.N && (unsigned)y < (unsigned)(isx ? p.Hl : p.Ho) &&
+                                        (unsigned)xq < (unsigned)(isx ? p.Wl : p.Wo);
+                        const int sh = isx ? p.up2 : 0;
+                        const int off = ((nn * (isx ? p.H : p.Ho) + (y >> sh)) * (isx ? p.W : p.Wo) + (xq >> sh)) * (isx ? p.Cin : p.Cout) +
+                                        (isx ? cix : cog);
+                        v[k] = ld16_or_zero(isx ? (const void*)x : (const void*)gy, (int64_t)off * 2, ok);
+                        if (MOD) {
+                            const float* sp = p.in_scale + ((isx && ok) ? nn * p.Cin + cix : 0);
+                            const float4 a0 = *reinterpret_cast<const float4*>(sp);
+                            const float4 a1 = *reinterpret_cast<const float4*>(sp + 4);
+                            const float4 one = make_float4(1.f, 1.f, 1.f, 1.f);
+                            s0[k] = isx ? a0 : one;
+                            s1[k] = isx ? a1 : one;
                         }
-                    } else if (idx < ntot) {
-                        const int j = idx - nxc;
-                        const int c8 = (j >> 3) & 7;
-                        const int P = (j >> 6) * 8 + (j & 7);
-                        const int b = P >> thw_log2;
-                        const int oy = oy0 + ((P >> TWL) & (TH - 1)), ox = ox0 + (P & (TW - 1));
-                        const int n = n0 + b, co = co0 + c8 * 8;
-                        dst[k] = 4 * PLX + (c8 >> 1) * PLG + P * 32 + (c8 & 1) * 16;
-                        if (n < p.N && oy < p.Ho && ox < p.Wo && co < p.Cout)
-                            v[k] = *reinterpret_cast<const uint4*>(gy + (((int64_t)n * p.Ho + oy) * p.Wo + ox) * p.Cout + co);
                     }
                 }
 #pragma unroll
-                for (int k = 0; k < TW_U; ++k) {
-                    if (dst[k] >= 0) {
+                for (int k = 0; k < U; ++k) {
+                    if (b0 + k < NSLOT) {
                         uint4 u = v[k];
-                        if (sc[k] >= 0) u = tmod_chunk(u, p.in_scale + sc[k]);
-                        *reinterpret_cast<uint4*>(xl + dst[k]) = u;
+                        if (MOD) {
+                            bf16x8 h = *reinterpret_cast<bf16x8*>(&u);
+                            h[0] = (bf16)((float)h[0] * s0[k].x); h[1] = (bf16)((float)h[1] * s0[k].y);
+                            h[2] = (bf16)((float)h[2] * s0[k].z); h[3] = (bf16)((float)h[3] * s0[k].w);
+                            h[4] = (bf16)((float)h[4] * s1[k].x); h[5] = (bf16)((float)h[5] * s1[k].y);
+                            h[6] = (bf16)((float)h[6] * s1[k].z); h[7] = (bf16)((float)h[7] * s1[k].w);
+                            u = *reinterpret_cast<uint4*>(&h);
+                        }
+                        const int d = dsto[b0 + k];
+                        *reinterpret_cast<uint4*>(xl + (d >= 0 ? d : dump)) = u;
                     }
                 }
             }
-            (void)gl;
             __syncthreads();  // stage ready; consumers have left the stage this overwrites two tiles later
         }
     } else {
@@ -275,7 +311,7 @@ TiledPlan plan_tiled(int N, int Ho, int Wo, int Cin, int Cout, int ks) {
     if (S > 65535) S = 65535;
     pl.S = S;
     const int NPX = NB * (TW + ks - 1) * (TH + ks - 1);
-    pl.lds = 2 * (4 * NPX * 32 + 4 * 128 * 32);  // two stages
+    pl.lds = 2 * (4 * NPX * 32 + 4 * 128 * 32) + 64 * TW_LOADERS * 16;  // two stages + the producers' dump slots
     if (ks == 1 && pl.lds < 3 * 4096 * 4) pl.lds = 3 * 4096 * 4;
     pl.ok = true;
     return pl;
@@ -287,6 +323,7 @@ TiledPlan plan_tiled(int N, int Ho, int Wo, int Cin, int Cout, int ks) {
 int64_t gan_wgrad_tiled_workspace(int N, int Ho, int Wo, int Cin, int Cout, int kh, int kw, int py, int px) {
     if (kh != kw || (kh != 1 && kh != 3) || py != (kh - 1) / 2 || px != py) return 0;
     if ((Cin & 7) || (Cout & 7)) return 0;
+    if ((int64_t)N * Ho * Wo * (Cin > Cout ? Cin : Cout) >= (1LL << 31)) return 0;  // 32-bit element offsets in the producers
     const TiledPlan pl = plan_tiled(N, Ho, Wo, Cin, Cout, kh);
     if (!pl.ok) return 0;
     return (int64_t)pl.S * kh * kw * Cout * Cin;
@@ -305,8 +342,13 @@ int gan_conv2d_wgrad_tiled(const void* x, const void* gy, float* dw, const float
     a.Ho = Ho; a.Wo = Wo; a.Cin = Cin; a.Cout = Cout; a.py = py; a.px = px;
     a.tiles_x = pl.tiles_x; a.tiles_y = pl.tiles_y; a.ntiles = pl.ntiles; a.S = pl.S; a.ci_tiles = pl.ci_tiles;
     const dim3 grid((unsigned)(pl.co_tiles * pl.ci_tiles), (unsigned)pl.S);
-#define TW_LAUNCH(KS_, TWL_, THL_, NBL_) \
-    hipLaunchKernelGGL((conv_wgrad_tiled_k<KS_, TWL_, THL_, NBL_>), grid, dim3(320), (size_t)pl.lds, st, a)
+#define TW_LAUNCH(KS_, TWL_, THL_, NBL_)                                                                                \
+    do {                                                                                                             \
+        if (in_scale)                                                                                                \
+            hipLaunchKernelGGL((conv_wgrad_tiled_k<KS_, TWL_, THL_, NBL_, true>), grid, dim3(320), (size_t)pl.lds, st, a);  \
+        else                                                                                                         \
+            hipLaunchKernelGGL((conv_wgrad_tiled_k<KS_, TWL_, THL_, NBL_, false>), grid, dim3(320), (size_t)pl.lds, st, a); \
+    } while (0)
     if (kh == 3) {
         if (pl.tw_log2 == 5) TW_LAUNCH(3, 5, 2, 0);
         else if (pl.tw_log2 == 4) TW_LAUNCH(3, 4, 3, 0);
