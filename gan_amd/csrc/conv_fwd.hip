@@ -158,7 +158,12 @@ __global__ void __launch_bounds__(256) conv_fwd_k(const ConvArgs p) {
     int dy = tap / p.kw;
     int dx = tap - dy * p.kw;
 
+    // Staging loads are unconditional (ld16_or_zero) and the modulation vectors are fetched beside them;
+    // the multiply happens when the tile is written to LDS one step later.  Loads under `if (ok)` were
+    // issued one branch + wait at a time.
     uint4 a_reg[NA], b_reg[NB];
+    constexpr int SPC = EPC / 4;  // float4 scale vectors per 16-byte chunk (2 for bf16, 1 for fp32)
+    float4 a_sc[NA][SPC];
 
     auto load_step = [&](int s) {
 #pragma unroll
@@ -166,22 +171,20 @@ __global__ void __launch_bounds__(256) conv_fwd_k(const ConvArgs p) {
             const int iy = a_oy[i] + dy - p.py;
             const int ix = a_ox[i] + dx - p.px;
             const bool ok = a_ok[i] && tap < ntaps && (unsigned)iy < (unsigned)p.Hl && (unsigned)ix < (unsigned)p.Wl;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (ok) {
-                const int64_t off = (((int64_t)a_n[i] * p.H + (iy >> p.up2)) * p.W + (ix >> p.up2)) * p.Cin + ci;
-                v = *reinterpret_cast<const uint4*>(x + off);
-                if (p.in_scale) v = scale_chunk(v, p.in_scale + (int64_t)a_n[i] * p.Cin + ci, T());
+            const int64_t off = (((int64_t)a_n[i] * p.H + (iy >> p.up2)) * p.W + (ix >> p.up2)) * p.Cin + ci;
+            a_reg[i] = ld16_or_zero(x, off * (int64_t)sizeof(T), ok);
+            if (p.in_scale) {
+                const float* sp = p.in_scale + (ok ? (int64_t)a_n[i] * p.Cin + ci : 0);
+#pragma unroll
+                for (int j = 0; j < SPC; ++j) a_sc[i][j] = *reinterpret_cast<const float4*>(sp + 4 * j);
             }
-            a_reg[i] = v;
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int row = (tid + i * 256) / CH;
             const int co = bn0 + row;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (row < BN && co < p.Cout)
-                v = *reinterpret_cast<const uint4*>(wt + (int64_t)co * p.Kpad + (int64_t)s * 32 + ch * EPC);
-            b_reg[i] = v;
+            const bool ok = row < BN && co < p.Cout;
+            b_reg[i] = ld16_or_zero(wt, ((int64_t)co * p.Kpad + (int64_t)s * 32 + ch * EPC) * (int64_t)sizeof(T), ok);
         }
         // advance the k tracker to the next step
         ci += 32;
@@ -201,7 +204,22 @@ __global__ void __launch_bounds__(256) conv_fwd_k(const ConvArgs p) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int row = (tid + i * 256) / CH;
-            if (row < BM) *reinterpret_cast<uint4*>(A + lds_off<T>(row, ch)) = a_reg[i];
+            uint4 v = a_reg[i];
+            if (p.in_scale) {
+                if constexpr (sizeof(T) == 2) {
+                    bf16x8 h = *reinterpret_cast<bf16x8*>(&v);
+                    h[0] = (bf16)((float)h[0] * a_sc[i][0].x); h[1] = (bf16)((float)h[1] * a_sc[i][0].y);
+                    h[2] = (bf16)((float)h[2] * a_sc[i][0].z); h[3] = (bf16)((float)h[3] * a_sc[i][0].w);
+                    h[4] = (bf16)((float)h[4] * a_sc[i][SPC - 1].x); h[5] = (bf16)((float)h[5] * a_sc[i][SPC - 1].y);
+                    h[6] = (bf16)((float)h[6] * a_sc[i][SPC - 1].z); h[7] = (bf16)((float)h[7] * a_sc[i][SPC - 1].w);
+                    v = *reinterpret_cast<uint4*>(&h);
+                } else {
+                    float4 f = *reinterpret_cast<float4*>(&v);
+                    f.x *= a_sc[i][0].x; f.y *= a_sc[i][0].y; f.z *= a_sc[i][0].z; f.w *= a_sc[i][0].w;
+                    v = *reinterpret_cast<uint4*>(&f);
+                }
+            }
+            if (row < BM) *reinterpret_cast<uint4*>(A + lds_off<T>(row, ch)) = v;
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {

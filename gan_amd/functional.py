@@ -19,6 +19,7 @@ these primitives.
 """
 from __future__ import annotations
 
+import weakref
 from typing import Optional, Tuple
 
 import torch
@@ -241,10 +242,11 @@ def _pad_channels(x: Tensor, mult: int) -> Tensor:
     return as_cl(F.pad(x, (0, 0, 0, 0, 0, rem)))
 
 
-def pack_weight(weight: Tensor, dtype: torch.dtype, cin_mult: int = 8) -> Tuple[Tensor, int, int]:
-    """(Cout, Cin, kh, kw) -> GEMM-B layout [Cout][Kpad], k = tap*Cin_p + ci, zero padded; returns (wt, Cin_p, Kpad)."""
+def _pack_weight(weight: Tensor, dtype: torch.dtype, cin_mult: int, transposed: bool) -> Tuple[Tensor, int, int]:
+    if transposed:  # the correlation whose result is the input gradient: swap channels, flip the taps
+        weight = weight.flip(2, 3).transpose(0, 1)
     cout, cin, kh, kw = weight.shape
-    w = weight.detach().permute(0, 2, 3, 1)  # (Cout, kh, kw, Cin)
+    w = weight.permute(0, 2, 3, 1)  # (Cout, kh, kw, Cin)
     cin_p = cin + ((-cin) % cin_mult)
     if cin_p != cin:
         w = F.pad(w, (0, cin_p - cin))
@@ -254,6 +256,33 @@ def pack_weight(weight: Tensor, dtype: torch.dtype, cin_mult: int = 8) -> Tuple[
     if kpad != k:
         w = F.pad(w, (0, kpad - k))
     return w.to(dtype).contiguous(), cin_p, kpad
+
+
+# Packed GEMM-B images of the PARAMETERS, reused until the optimizer's in-place update bumps the tensor
+# version: one conv weight is packed ~10 times per training step otherwise (forward on reals and fakes,
+# both input gradients, the double-backward convolutions), ~4 tiny launches each.
+_PACK_CACHE: dict = {}
+
+
+def pack_weight(weight: Tensor, dtype: torch.dtype, cin_mult: int = 8, transposed: bool = False) -> Tuple[Tensor, int, int]:
+    """(Cout, Cin, kh, kw) -> GEMM-B layout [Cout][Kpad], k = tap*Cin_p + ci, zero padded; returns (wt, Cin_p, Kpad).
+    `transposed` packs the flipped, channel-swapped weights of the input-gradient correlation."""
+    if not (weight.is_leaf and weight.requires_grad) or weight.numel() == 0:
+        return _pack_weight(weight.detach(), dtype, cin_mult, transposed)
+    key = (id(weight), dtype, cin_mult, transposed)
+    hit = _PACK_CACHE.get(key)
+    if hit is not None and hit[0]() is weight and hit[1] == weight._version:
+        PACK_STATS[0] += 1
+        return hit[2]
+    PACK_STATS[1] += 1
+    if len(_PACK_CACHE) > 4096:
+        _PACK_CACHE.clear()
+    packed = _pack_weight(weight.detach(), dtype, cin_mult, transposed)
+    _PACK_CACHE[key] = (weakref.ref(weight), weight._version, packed)
+    return packed
+
+
+PACK_STATS = [0, 0]  # hits, misses (cacheable tensors only)
 
 
 def raw_conv2d(
@@ -269,14 +298,18 @@ def raw_conv2d(
     noise: Optional[Tensor] = None,
     noise_scale: Optional[Tensor] = None,
     slope: float = 1.0,
+    transposed: bool = False,
 ) -> Tensor:
-    """Stride-1 correlation of channels-last x with weight (Cout, Cin, kh, kw) + fused prologue/epilogue."""
+    """Stride-1 correlation of channels-last x with weight (Cout, Cin, kh, kw) + fused prologue/epilogue.
+    `transposed`: correlate with the flipped, channel-swapped weights instead (weight is (Cin, Cout, kh, kw))."""
     require_gpu(x, weight, in_scale, out_scale, bias, noise, noise_scale)
     lib = _lib.load()
     x = _pad_channels(x.detach(), 8)
     n, cin_p, h, w = x.shape
     cout, cin, kh, kw = weight.shape
-    wt, cin_p2, kpad = pack_weight(weight, x.dtype)
+    if transposed:
+        cout, cin = cin, cout
+    wt, cin_p2, kpad = pack_weight(weight, x.dtype, transposed=transposed)
     if cin_p2 != cin_p:
         raise _lib.GanAmdError(f"conv2d: input has {x.shape[1]} (padded) channels, weight expects {cin}")
     hl, wl = (2 * h, 2 * w) if up2 else (h, w)
@@ -313,8 +346,7 @@ def raw_conv2d_dgrad(gy: Tensor, weight: Tensor, py: int, px: int, *, out_scale:
     """Input gradient of a stride-1 correlation = correlation of gy with the transposed, flipped
     weights and padding k-1-p.  Output spatial size is the forward input size."""
     cout, cin, kh, kw = weight.shape
-    wt = weight.detach().flip(2, 3).transpose(0, 1)  # (Cin, Cout, kh, kw)
-    return raw_conv2d(gy, wt, kh - 1 - py, kw - 1 - px, out_scale=out_scale)
+    return raw_conv2d(gy, weight, kh - 1 - py, kw - 1 - px, out_scale=out_scale, transposed=True)
 
 
 def raw_conv2d_wgrad(
