@@ -101,23 +101,55 @@ __device__ __forceinline__ uint4 ld16_or_zero(const void* base, int64_t elem_off
 __device__ __forceinline__ float lrelu_f(float v, float slope) { return v > 0.f ? v : v * slope; }
 __device__ __forceinline__ float lrelu_mask(float y, float slope) { return y > 0.f ? 1.f : slope; }
 
+// leaky-ReLU of a 16-byte chunk on its way into LDS (the activation that precedes a convolution)
+__device__ __forceinline__ uint4 lrelu_chunk(uint4 raw, float slope, bf16) {
+    bf16x8 v = *reinterpret_cast<bf16x8*>(&raw);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (bf16)lrelu_f((float)v[j], slope);
+    return *reinterpret_cast<uint4*>(&v);
+}
+__device__ __forceinline__ uint4 lrelu_chunk(uint4 raw, float slope, float) {
+    float4 v = *reinterpret_cast<float4*>(&raw);
+    v.x = lrelu_f(v.x, slope); v.y = lrelu_f(v.y, slope); v.z = lrelu_f(v.z, slope); v.w = lrelu_f(v.w, slope);
+    return *reinterpret_cast<uint4*>(&v);
+}
+
+// The fused stages around a convolution beyond modulation / bias / noise / activation (include/gan_amd.h):
+// leaky-ReLU of the input as it is staged, 2x2 average pooling of the result, a final multiply by the
+// leaky-ReLU derivative mask of `aux` (a tensor shaped like the output), and a scalar gain.
+struct ConvFuse {
+    float in_slope;   // 1 = no input activation
+    int pool;         // 1 = 2x2 average pooling; bias / noise / aux / y are at the pooled resolution
+    const void* aux;  // nullptr = no mask
+    float aux_slope;
+    float gain;
+};
+
 // conv_thin.hip: direct convolution for thin layers (bf16).  1 = served, 0 = shape not eligible, < 0 = error.
 int gan_conv2d_fwd_thin(const void* x, const void* wt, void* y, const float* in_scale, const float* out_scale,
                         const float* bias, const void* noise, const float* noise_scale, float slope, int N, int H,
                         int W, int Cin, int up2, int Ho, int Wo, int Cout, int kh, int kw, int py, int px, int Kpad,
-                        hipStream_t st);
+                        const ConvFuse& fu, hipStream_t st);
+
+// Fused stages of the weight gradient (include/gan_amd.h): leaky-ReLU of x as it is staged, gy given at half
+// resolution (nearest-neighbour upsampled in the gather: the adjoint of 2x2 pooling, with gain 0.25), scalar gain.
+struct WgradFuse {
+    float x_slope;  // 1 = none
+    int gy_up2;
+    float gain;
+};
 
 // conv_thin_wgrad.hip: weight gradient for thin layers (bf16); dw must be zeroed by the caller.
 int gan_conv2d_wgrad_thin(const void* x, const void* gy, float* dw, const float* in_scale, int N, int H, int W,
                           int Cin, int up2, int Ho, int Wo, int Cout, int kh, int kw, int py, int px, float* ws,
-                          int64_t ws_floats, int64_t* need, hipStream_t st);
+                          int64_t ws_floats, int64_t* need, const WgradFuse& fu, hipStream_t st);
 // conv_wgrad_tiled.hip: weight gradient for wide layers / small maps (bf16, needs a workspace) and the
 // slice reducer out[e] += sum_s ws[s][e].
 int64_t gan_wgrad_tiled_workspace(int N, int Ho, int Wo, int Cin, int Cout, int kh, int kw, int py, int px);
 int gan_conv2d_wgrad_tiled(const void* x, const void* gy, float* dw, const float* in_scale, int N, int H, int W,
                            int Cin, int up2, int Ho, int Wo, int Cout, int kh, int kw, int py, int px, float* ws,
-                           int64_t ws_floats, hipStream_t st);
-int gan_reduce_slices(const float* ws, float* out, int64_t L, int S, hipStream_t st);
+                           int64_t ws_floats, const WgradFuse& fu, hipStream_t st);
+int gan_reduce_slices(const float* ws, float* out, int64_t L, int S, float gain, hipStream_t st);
 
 // upfirdn_mfma.hip: bf16 upfirdn2d with the FIR as banded matrix products on MFMA.  1 / 0 / < 0 as above.
 int gan_upfirdn2d_mfma(const void* x, const float* taps, void* y, int N, int H, int W, int C, int ky, int kx, int up,

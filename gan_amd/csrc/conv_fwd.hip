@@ -33,6 +33,7 @@ struct ConvArgs {
     int kh, kw, py, px;
     int Kpad, ksteps;
     int64_t M;
+    ConvFuse fu;
 };
 
 template <typename T>
@@ -148,8 +149,17 @@ __global__ void __launch_bounds__(256) conv_fwd_k(const ConvArgs p) {
         const int n = (int)(mm / HoWo);
         const int rem = (int)(mm - (int64_t)n * HoWo);
         a_n[i] = n;
-        a_oy[i] = rem / p.Wo;
-        a_ox[i] = rem - a_oy[i] * p.Wo;
+        if (p.fu.pool) {
+            // pooled launches order the GEMM rows quad-major: rows 4q..4q+3 are the 2x2 window of pooled
+            // pixel q, so the window ends up in ONE lane's four accumulator registers
+            const int q = rem >> 2, wo2 = p.Wo >> 1;
+            const int qy = q / wo2;
+            a_oy[i] = 2 * qy + ((rem >> 1) & 1);
+            a_ox[i] = 2 * (q - qy * wo2) + (rem & 1);
+        } else {
+            a_oy[i] = rem / p.Wo;
+            a_ox[i] = rem - a_oy[i] * p.Wo;
+        }
     }
     // running (tap, ci) of this thread's chunk; advances by 32 elements per K step
     int kelem = ch * EPC;
@@ -205,6 +215,7 @@ __global__ void __launch_bounds__(256) conv_fwd_k(const ConvArgs p) {
         for (int i = 0; i < NA; ++i) {
             const int row = (tid + i * 256) / CH;
             uint4 v = a_reg[i];
+            if (p.fu.in_slope != 1.f) v = lrelu_chunk(v, p.fu.in_slope, T());
             if (p.in_scale) {
                 if constexpr (sizeof(T) == 2) {
                     bf16x8 h = *reinterpret_cast<bf16x8*>(&v);
@@ -271,23 +282,30 @@ __global__ void __launch_bounds__(256) conv_fwd_k(const ConvArgs p) {
     // ---- epilogue: D layout col = lane&15 (co), row = (lane>>4)*4 + r (pixel) -------------
     T* __restrict__ y = (T*)p.y;
     const T* __restrict__ noise = (const T*)p.noise;
+    const T* __restrict__ aux = (const T*)p.fu.aux;
+    const int nr = p.fu.pool ? 1 : 4;               // pooled: the lane's four rows are one 2x2 window
+    const int out_per_img = p.fu.pool ? HoWo >> 2 : HoWo;
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
+        const int64_t mrow = bm0 + wm * TM + i * 16 + fq * 4;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int64_t m = bm0 + wm * TM + i * 16 + fq * 4 + r;
-            if (m >= p.M) continue;
-            const int n = (int)(m / HoWo);
+            if (r >= nr || mrow + r >= p.M) continue;
+            const int64_t m = p.fu.pool ? (mrow >> 2) : mrow + r;  // output pixel
+            const int n = (int)(m / out_per_img);
             const float nz = noise ? (float)noise[m] : 0.f;
 #pragma unroll
             for (int j = 0; j < FN; ++j) {
                 const int co = bn0 + wn * TN + j * 16 + frow;
                 if (co >= p.Cout) continue;
-                float v = acc[i][j][r];
+                const f32x4 a4 = acc[i][j];
+                float v = p.fu.pool ? 0.25f * ((a4[0] + a4[1]) + (a4[2] + a4[3])) : a4[r];
+                v *= p.fu.gain;
                 if (p.out_scale) v *= p.out_scale[(int64_t)n * p.Cout + co];
                 if (p.bias) v += p.bias[co];
                 if (noise) v = fmaf(nz, p.noise_scale[co], v);
                 v = lrelu_f(v, p.slope);
+                if (aux) v *= lrelu_mask((float)aux[m * p.Cout + co], p.fu.aux_slope);
                 y[m * p.Cout + co] = (T)v;
             }
         }
@@ -333,7 +351,8 @@ int launch(const ConvArgs& a, hipStream_t st) {
 extern "C" int gan_conv2d_fwd(const void* x, const void* wt, void* y, const float* in_scale, const float* out_scale,
                               const float* bias, const void* noise, const float* noise_scale, float slope, int N,
                               int H, int W, int Cin, int up2, int Ho, int Wo, int Cout, int kh, int kw, int py, int px,
-                              int Kpad, int dtype, gan_stream_t stream) {
+                              int Kpad, float in_slope, int pool, const void* aux, float aux_slope, float gain,
+                              int dtype, gan_stream_t stream) {
     GAN_CHECK_ARG(N == 0 || (x && wt && y), "conv2d_fwd: null pointer");
     GAN_CHECK_ARG(dtype == GAN_F32 || dtype == GAN_BF16, "conv2d_fwd: bad dtype %d", dtype);
     GAN_CHECK_ARG(N >= 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Ho > 0 && Wo > 0, "conv2d_fwd: bad shape");
@@ -348,8 +367,10 @@ extern "C" int gan_conv2d_fwd(const void* x, const void* wt, void* y, const floa
                   "conv2d_fwd: output %dx%d does not match input %dx%d, kernel %dx%d, pad %d,%d", Ho, Wo, Hl, Wl, kh,
                   kw, py, px);
     GAN_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)wt % 16) == 0, "conv2d_fwd: x and wt must be 16-byte aligned");
+    GAN_CHECK_ARG(pool == 0 || (pool == 1 && Ho % 2 == 0 && Wo % 2 == 0), "conv2d_fwd: pooling needs an even %dx%d output", Ho, Wo);
     if (N == 0) return GAN_OK;
     ConvArgs a;
+    a.fu.in_slope = in_slope; a.fu.pool = pool; a.fu.aux = aux; a.fu.aux_slope = aux_slope; a.fu.gain = gain;
     a.x = x; a.wt = wt; a.y = y;
     a.in_scale = in_scale; a.out_scale = out_scale; a.bias = bias;
     a.noise = noise; a.noise_scale = noise_scale; a.slope = slope;
@@ -362,7 +383,7 @@ extern "C" int gan_conv2d_fwd(const void* x, const void* wt, void* y, const floa
     if (dtype == GAN_F32) return launch<float>(a, st);
     // thin layers (Cin, Cout <= 64 at >= 32 pixels wide) are HBM-bound: halo-tiled direct kernel
     const int thin = gan_conv2d_fwd_thin(x, wt, y, in_scale, out_scale, bias, noise, noise_scale, slope, N, H, W, Cin,
-                                         up2, Ho, Wo, Cout, kh, kw, py, px, Kpad, st);
+                                         up2, Ho, Wo, Cout, kh, kw, py, px, Kpad, a.fu, st);
     if (thin != 0) return thin < 0 ? thin : GAN_OK;
     return launch<bf16>(a, st);
 }

@@ -35,6 +35,7 @@ struct ThinArgs {
     float slope;
     int N, H, W, Hl, Wl, up2, Ho, Wo, Cout, py, px, Kpad;
     int tiles_x, tiles_y;
+    ConvFuse fu;
 };
 
 __device__ __forceinline__ uint4 mod_chunk(uint4 raw, const float* s) {
@@ -64,7 +65,8 @@ struct ThinCfg {
     static constexpr int NLD = (NCHUNK + 255) / 256;
     static constexpr int X_BYTES = CP * PLANE;
     static constexpr int W_BYTES = KPAD * COUT * 2;
-    static constexpr int LDS_BYTES = X_BYTES + W_BYTES;
+    static constexpr int P_BYTES = 3 * COUT * 4;  // bias, noise scale, this tile's demodulation row (fp32)
+    static constexpr int LDS_BYTES = X_BYTES + W_BYTES + P_BYTES;
 };
 
 template <int CIN, int COUT, int KS, int RPW>
@@ -76,6 +78,10 @@ __global__ void __launch_bounds__(256) conv_thin_k(const ThinArgs p) {
     __shared__ __attribute__((aligned(256))) char lds[C::LDS_BYTES];
     char* const xl = lds;
     char* const wl = lds + C::X_BYTES;
+    // Per-channel epilogue vectors live in LDS: read back with ds_read (lgkmcnt).  As global loads inside
+    // the store loop each one made the compiler wait for vmcnt(0), i.e. for the PREVIOUS 8-byte store to
+    // complete and for the prefetched halo: eight store round trips per tile, 10 us a tile.
+    float* const pl = reinterpret_cast<float*>(lds + C::X_BYTES + C::W_BYTES);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -91,6 +97,10 @@ __global__ void __launch_bounds__(256) conv_thin_k(const ThinArgs p) {
         if (co < p.Cout) v = *reinterpret_cast<const uint4*>(wt + (int64_t)co * p.Kpad + kc * 8);
         *reinterpret_cast<uint4*>(wl + idx * 16) = v;
     }
+    if (tid < COUT) {
+        pl[tid] = (p.bias && tid < p.Cout) ? p.bias[tid] : 0.f;
+        pl[COUT + tid] = (p.noise_scale && tid < p.Cout) ? p.noise_scale[tid] : 0.f;
+    }
 
     const int tiles_per_img = p.tiles_x * p.tiles_y;
     const int64_t ntiles = (int64_t)tiles_per_img * p.N;
@@ -100,6 +110,7 @@ __global__ void __launch_bounds__(256) conv_thin_k(const ThinArgs p) {
     // ---- halo loader: chunk idx -> (pixel, channel chunk); 8 consecutive lanes = 8 consecutive
     // pixels of one chunk plane (conflict-free ds_write_b128), 8*CP lanes = one contiguous run ----
     uint4 reg[NLD];
+    float osc_reg = 1.f;
     unsigned okmask = 0;
     int n_ld = 0;
     auto issue = [&](int64_t t) {
@@ -109,6 +120,7 @@ __global__ void __launch_bounds__(256) conv_thin_k(const ThinArgs p) {
         const int ly0 = ty * TH - p.py, lx0 = tx * 32 - p.px;
         n_ld = n;
         okmask = 0;
+        if (p.out_scale) osc_reg = p.out_scale[(int64_t)n * p.Cout + (tid < p.Cout ? tid : 0)];
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             const int idx = i * 256 + tid;
@@ -128,6 +140,7 @@ __global__ void __launch_bounds__(256) conv_thin_k(const ThinArgs p) {
         }
     };
     auto commit = [&]() {
+        if (tid < COUT) pl[2 * COUT + tid] = osc_reg;
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             const int idx = i * 256 + tid;
@@ -136,6 +149,7 @@ __global__ void __launch_bounds__(256) conv_thin_k(const ThinArgs p) {
             const int pix = p8 * 8 + (r8 & 7);
             if (pix < NPIX) {
                 uint4 v = reg[i];
+                if (p.fu.in_slope != 1.f) v = lrelu_chunk(v, p.fu.in_slope, bf16());
                 if (p.in_scale && ((okmask >> i) & 1)) v = mod_chunk(v, p.in_scale + (int64_t)n_ld * CIN + c * 8);
                 *reinterpret_cast<uint4*>(xl + c * PLANE + pix * 16) = v;
             }
@@ -186,46 +200,93 @@ __global__ void __launch_bounds__(256) conv_thin_k(const ThinArgs p) {
         // ---- epilogue: lane holds channels co0..co0+3 (co0 = 16*i + 4*kg) of pixel (oy, ox) ------
         const int rem = (int)(t - (int64_t)n * tiles_per_img);
         const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
+        // Output slots of this lane: NE pixels x FCO channel quads.  Unpooled: slot e = fragment f.  Pooled: the
+        // 2x2 average has its row pair in this lane (fragments f, f+2) and its column pair in lane^1.
+        const bool pool = p.fu.pool != 0;
+        const int OH = pool ? p.Ho >> 1 : p.Ho, OW = pool ? p.Wo >> 1 : p.Wo;
+        const float gain = pool ? 0.25f * p.fu.gain : p.fu.gain;
+        const bf16* __restrict__ aux = (const bf16*)p.fu.aux;
+        // Batches of EB slots: FIRST every per-pixel global load of the batch (noise, mask), THEN the stores, so
+        // the wait for those loads is paid once per batch and never sits between two stores.
+        constexpr int EB = FCO >= 4 ? 1 : 4 / FCO;
 #pragma unroll
-        for (int f = 0; f < FPX; ++f) {
-            const int oy = ty * TH + wave * RPW + (f >> 1);
-            const int ox = tx * 32 + 16 * (f & 1) + lpx;
-            if (oy >= p.Ho || ox >= p.Wo) continue;
-            const int64_t m = ((int64_t)n * p.Ho + oy) * p.Wo + ox;
-            const float nz = noise ? (float)noise[m] : 0.f;
+        for (int e0 = 0; e0 < FPX; e0 += EB) {
+            float nz[EB];
+            uint2 ax[EB][FCO];
+            int mm[EB];
 #pragma unroll
-            for (int i = 0; i < FCO; ++i) {
-                const int co0 = i * 16 + kg * 4;
-                if (co0 >= p.Cout) continue;
-                float v[4] = {acc[i][f][0], acc[i][f][1], acc[i][f][2], acc[i][f][3]};
-                if (vec_store) {
-                    if (p.out_scale) {
-                        const float4 d = *reinterpret_cast<const float4*>(p.out_scale + (int64_t)n * p.Cout + co0);
-                        v[0] *= d.x; v[1] *= d.y; v[2] *= d.z; v[3] *= d.w;
-                    }
-                    if (p.bias) {
-                        const float4 b4 = *reinterpret_cast<const float4*>(p.bias + co0);
-                        v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
-                    }
-                    if (noise) {
-                        const float4 s4 = *reinterpret_cast<const float4*>(p.noise_scale + co0);
-                        v[0] = fmaf(nz, s4.x, v[0]); v[1] = fmaf(nz, s4.y, v[1]);
-                        v[2] = fmaf(nz, s4.z, v[2]); v[3] = fmaf(nz, s4.w, v[3]);
-                    }
-                    bf16x4 o;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) o[j] = (bf16)lrelu_f(v[j], p.slope);
-                    *reinterpret_cast<bf16x4*>(y + m * p.Cout + co0) = o;
+            for (int k = 0; k < EB; ++k) {
+                const int e = e0 + k;
+                int oy, ox;
+                bool live;
+                if (pool) {
+                    oy = (ty * TH + wave * RPW) / 2 + (e >> 1);
+                    ox = tx * 16 + 8 * (e & 1) + (lpx >> 1);
+                    live = e < RPW && (lpx & 1) == 0;
                 } else {
+                    oy = ty * TH + wave * RPW + (e >> 1);
+                    ox = tx * 32 + 16 * (e & 1) + lpx;
+                    live = true;
+                }
+                live = live && oy < OH && ox < OW;
+                mm[k] = live ? (n * OH + oy) * OW + ox : -1;
+                const int64_t ms = live ? mm[k] : 0;
+                nz[k] = noise ? (float)noise[ms] : 0.f;
+                if (aux && vec_store) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int co = co0 + j;
-                        if (co >= p.Cout) continue;
-                        float u = v[j];
-                        if (p.out_scale) u *= p.out_scale[(int64_t)n * p.Cout + co];
-                        if (p.bias) u += p.bias[co];
-                        if (noise) u = fmaf(nz, p.noise_scale[co], u);
-                        y[m * p.Cout + co] = (bf16)lrelu_f(u, p.slope);
+                    for (int i = 0; i < FCO; ++i) {
+                        const int co0 = i * 16 + kg * 4;
+                        ax[k][i] = *reinterpret_cast<const uint2*>(aux + (co0 < p.Cout ? ms * p.Cout + co0 : 0));
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < EB; ++k) {
+                const int e = e0 + k;
+#pragma unroll
+                for (int i = 0; i < FCO; ++i) {
+                    const int co0 = i * 16 + kg * 4;
+                    float v[4];
+                    if (pool) {
+                        // executed by every lane (the shuffle needs its partner); fragments past RPW are not slots
+                        const int fa = e < RPW ? 4 * (e >> 1) + (e & 1) : 0;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float a = acc[i][fa][j] + acc[i][fa + 2][j];
+                            v[j] = (a + __shfl_xor(a, 1)) * gain;
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = acc[i][e][j] * gain;
+                    }
+                    const int64_t m = mm[k];
+                    if (mm[k] < 0 || co0 >= p.Cout) continue;
+                    const float4 b4 = *reinterpret_cast<const float4*>(pl + co0);
+                    const float4 s4 = *reinterpret_cast<const float4*>(pl + COUT + co0);
+                    const float4 d4 = *reinterpret_cast<const float4*>(pl + 2 * COUT + co0);
+                    const float bb[4] = {b4.x, b4.y, b4.z, b4.w}, ss[4] = {s4.x, s4.y, s4.z, s4.w};
+                    const float dd[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = lrelu_f(fmaf(nz[k], ss[j], fmaf(v[j], dd[j], bb[j])), p.slope);
+                    if (vec_store) {
+                        if (aux) {
+                            const bf16x4 a4 = *reinterpret_cast<const bf16x4*>(&ax[k][i]);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) v[j] *= lrelu_mask((float)a4[j], p.fu.aux_slope);
+                        }
+                        bf16x4 o;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) o[j] = (bf16)v[j];
+                        *reinterpret_cast<bf16x4*>(y + m * p.Cout + co0) = o;
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int co = co0 + j;
+                            if (co >= p.Cout) continue;
+                            float u = v[j];
+                            if (aux) u *= lrelu_mask((float)aux[m * p.Cout + co], p.fu.aux_slope);
+                            y[m * p.Cout + co] = (bf16)u;
+                        }
                     }
                 }
             }
@@ -273,14 +334,15 @@ int pick_cin(const ThinArgs& a, int Cin, hipStream_t st) {
 int gan_conv2d_fwd_thin(const void* x, const void* wt, void* y, const float* in_scale, const float* out_scale,
                         const float* bias, const void* noise, const float* noise_scale, float slope, int N, int H,
                         int W, int Cin, int up2, int Ho, int Wo, int Cout, int kh, int kw, int py, int px, int Kpad,
-                        hipStream_t st) {
+                        const ConvFuse& fu, hipStream_t st) {
     if (kh != kw || (kh != 1 && kh != 3)) return 0;
     if (py != (kh - 1) / 2 || px != py) return 0;
     if (Cin != 8 && Cin != 16 && Cin != 32 && Cin != 64) return 0;
     if (Cout > 64 || Wo < 32 || Ho < 8) return 0;
     if (Kpad != (kh * kw * Cin + 31) / 32 * 32) return 0;
-    if (((uintptr_t)y % 8) != 0) return 0;
+    if (((uintptr_t)y % 8) != 0 || ((uintptr_t)fu.aux % 8) != 0) return 0;
     ThinArgs a;
+    a.fu = fu;
     a.x = x; a.wt = wt; a.y = y;
     a.in_scale = in_scale; a.out_scale = out_scale; a.bias = bias;
     a.noise = noise; a.noise_scale = noise_scale; a.slope = slope;

@@ -27,6 +27,7 @@ struct ThinWArgs {
     int N, H, W, Hl, Wl, up2, Ho, Wo, Cin, Cout, py, px;
     int tiles_x, tiles_y;
     float* ws;  // optional [gridDim.x * WR][taps][Cout][Cin] partial slices (plain stores) instead of atomics
+    WgradFuse fu;
 };
 
 __device__ __forceinline__ uint4 wmod_chunk(uint4 raw, const float* s) {
@@ -72,9 +73,10 @@ __global__ void __launch_bounds__(256) conv_thin_wgrad_k(const ThinWArgs p) {
     constexpr int CGI = C::CGI, CGO = C::CGO, HWD = C::HWD, NPX = C::NPX, PLX = C::PLX, PLG = C::PLG;
     constexpr int ROWS = C::ROWS, NT = C::NT, CPX = CIN / 8, CPG = COUT / 8;
 
-    __shared__ __attribute__((aligned(256))) char lds[C::LDS_BYTES];
+    __shared__ __attribute__((aligned(256))) char lds[C::LDS_BYTES + 256 * 16];
     char* const xl = lds;
     char* const gl = lds + C::X_BYTES;
+    char* const dumpl = lds + C::LDS_BYTES;  // per-thread 16-byte slot for staging chunks past the tile
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -105,33 +107,69 @@ __global__ void __launch_bounds__(256) conv_thin_wgrad_k(const ThinWArgs p) {
         const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
         const int oy0 = ty * TH, ox0 = tx * 32;
         __syncthreads();  // previous tile's fragment reads are done
+        // Staging is branch-free: batches of UB unconditional 16-byte loads (ld16_or_zero), then the LDS
+        // stores; chunk indices past the image go to a per-thread dump slot.
+        constexpr int UB = 8;
+        constexpr int NLX = (C::NCX + 255) / 256, NLG = (C::NCG + 255) / 256;
         // ---- x halo -> LDS [ci/16][pixel][16] ------------------------------------------------
-        for (int idx = tid; idx < C::NCX; idx += 256) {
-            const int p8 = idx / (8 * CPX), r8 = idx % (8 * CPX);
-            const int c8 = r8 >> 3;
-            const int pix = p8 * 8 + (r8 & 7);
-            if (pix >= NPX) continue;
-            const int hy = pix / HWD, hx = pix - hy * HWD;
-            const int ly = oy0 - p.py + hy, lx = ox0 - p.px + hx;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if ((unsigned)ly < (unsigned)p.Hl && (unsigned)lx < (unsigned)p.Wl && c8 * 8 < p.Cin) {
+#pragma unroll
+        for (int b0 = 0; b0 < NLX; b0 += UB) {
+            uint4 v[UB];
+#pragma unroll
+            for (int k = 0; k < UB; ++k) {
+                if (b0 + k >= NLX) continue;
+                const int idx = (b0 + k) * 256 + tid;
+                const int p8 = idx / (8 * CPX), r8 = idx % (8 * CPX);
+                const int c8 = r8 >> 3;
+                const int pix = p8 * 8 + (r8 & 7);
+                const int hy = pix / HWD, hx = pix - hy * HWD;
+                const int ly = oy0 - p.py + hy, lx = ox0 - p.px + hx;
+                const bool ok = pix < NPX && (unsigned)ly < (unsigned)p.Hl && (unsigned)lx < (unsigned)p.Wl && c8 * 8 < p.Cin;
                 const int64_t off = (((int64_t)n * p.H + (ly >> p.up2)) * p.W + (lx >> p.up2)) * p.Cin + c8 * 8;
-                v = *reinterpret_cast<const uint4*>(x + off);
-                if (p.in_scale) v = wmod_chunk(v, p.in_scale + (int64_t)n * p.Cin + c8 * 8);
+                v[k] = ld16_or_zero(x, off * 2, ok);
             }
-            *reinterpret_cast<uint4*>(xl + (c8 >> 1) * PLX + pix * 32 + (c8 & 1) * 16) = v;
+#pragma unroll
+            for (int k = 0; k < UB; ++k) {
+                if (b0 + k >= NLX) continue;
+                const int idx = (b0 + k) * 256 + tid;
+                const int p8 = idx / (8 * CPX), r8 = idx % (8 * CPX);
+                const int c8 = r8 >> 3;
+                const int pix = p8 * 8 + (r8 & 7);
+                uint4 u = v[k];
+                if (p.fu.x_slope != 1.f) u = lrelu_chunk(u, p.fu.x_slope, bf16());
+                if (p.in_scale) u = wmod_chunk(u, p.in_scale + (int64_t)n * p.Cin + (c8 * 8 < p.Cin ? c8 * 8 : 0));
+                char* const dst = pix < NPX ? xl + (c8 >> 1) * PLX + pix * 32 + (c8 & 1) * 16 : dumpl + tid * 16;
+                *reinterpret_cast<uint4*>(dst) = u;
+            }
         }
-        // ---- gy tile -> LDS [co/16][pixel][16] ------------------------------------------------
-        for (int idx = tid; idx < C::NCG; idx += 256) {
-            const int p8 = idx / (8 * CPG), r8 = idx % (8 * CPG);
-            const int c8 = r8 >> 3;
-            const int pix = p8 * 8 + (r8 & 7);
-            const int ry = pix >> 5, rx = pix & 31;
-            const int oy = oy0 + ry, ox = ox0 + rx;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (oy < p.Ho && ox < p.Wo && c8 * 8 < p.Cout)
-                v = *reinterpret_cast<const uint4*>(gy + (((int64_t)n * p.Ho + oy) * p.Wo + ox) * p.Cout + c8 * 8);
-            *reinterpret_cast<uint4*>(gl + (c8 >> 1) * PLG + pix * 32 + (c8 & 1) * 16) = v;
+        // ---- gy tile -> LDS [co/16][pixel][16] (gy_up2: gy is stored at half resolution) --------
+        const int gsh = p.fu.gy_up2;
+        const int Hg = p.Ho >> gsh, Wg = p.Wo >> gsh;
+#pragma unroll
+        for (int b0 = 0; b0 < NLG; b0 += UB) {
+            uint4 v[UB];
+#pragma unroll
+            for (int k = 0; k < UB; ++k) {
+                if (b0 + k >= NLG) continue;
+                const int idx = (b0 + k) * 256 + tid;
+                const int p8 = idx / (8 * CPG), r8 = idx % (8 * CPG);
+                const int c8 = r8 >> 3;
+                const int pix = p8 * 8 + (r8 & 7);
+                const int oy = oy0 + (pix >> 5), ox = ox0 + (pix & 31);
+                const bool ok = idx < C::NCG && oy < p.Ho && ox < p.Wo && c8 * 8 < p.Cout;
+                const int64_t off = (((int64_t)n * Hg + (oy >> gsh)) * Wg + (ox >> gsh)) * p.Cout + c8 * 8;
+                v[k] = ld16_or_zero(gy, off * 2, ok);
+            }
+#pragma unroll
+            for (int k = 0; k < UB; ++k) {
+                if (b0 + k >= NLG) continue;
+                const int idx = (b0 + k) * 256 + tid;
+                const int p8 = idx / (8 * CPG), r8 = idx % (8 * CPG);
+                const int c8 = r8 >> 3;
+                const int pix = p8 * 8 + (r8 & 7);
+                char* const dst = idx < C::NCG ? gl + (c8 >> 1) * PLG + pix * 32 + (c8 & 1) * 16 : dumpl + tid * 16;
+                *reinterpret_cast<uint4*>(dst) = v[k];
+            }
         }
         __syncthreads();
 
@@ -180,9 +218,9 @@ __global__ void __launch_bounds__(256) conv_thin_wgrad_k(const ThinWArgs p) {
                         const int ci = i * 16 + li;
                         if (co < p.Cout && ci < p.Cin) {
                             if (p.ws)
-                                dwt[(int64_t)co * p.Cin + ci] = acc[j][o][i][r];
+                                dwt[(int64_t)co * p.Cin + ci] = acc[j][o][i][r];  // gain: in the slice reducer
                             else
-                                atomicAdd(dwt + (int64_t)co * p.Cin + ci, acc[j][o][i][r]);
+                                atomicAdd(dwt + (int64_t)co * p.Cin + ci, acc[j][o][i][r] * p.fu.gain);
                         }
                     }
         }
@@ -193,12 +231,12 @@ __global__ void __launch_bounds__(256) conv_thin_wgrad_k(const ThinWArgs p) {
 template <int CIN, int COUT, int KS, int TH, int WT>
 int launch_thin_w(ThinWArgs a, int64_t ws_floats, int64_t* need, hipStream_t st) {
     typedef ThinWCfg<CIN, COUT, KS, TH, WT> C;
-    static_assert(C::LDS_BYTES <= 160 * 1024, "tile does not fit LDS");
+    static_assert(C::LDS_BYTES + 4096 <= 160 * 1024, "tile does not fit LDS");
     static_assert(TH % C::WR == 0, "rows must split evenly over the row groups");
     a.tiles_x = (a.Wo + 31) / 32;
     a.tiles_y = (a.Ho + TH - 1) / TH;
     const int64_t ntiles = (int64_t)a.tiles_x * a.tiles_y * a.N;
-    int per_cu = (160 * 1024) / C::LDS_BYTES;
+    int per_cu = (160 * 1024) / (C::LDS_BYTES + 4096);
     if (per_cu > 4) per_cu = 4;
     if (per_cu < 1) per_cu = 1;
     int64_t grid = 256LL * per_cu;
@@ -213,7 +251,7 @@ int launch_thin_w(ThinWArgs a, int64_t ws_floats, int64_t* need, hipStream_t st)
     if (!use_ws) a.ws = nullptr;
     hipLaunchKernelGGL((conv_thin_wgrad_k<CIN, COUT, KS, TH, WT>), dim3((unsigned)grid), dim3(256), 0, st, a);
     GAN_CHECK_LAUNCH("conv2d_wgrad(thin)");
-    if (use_ws) return gan_reduce_slices(a.ws, a.dw, L, (int)(grid * C::WR), st);
+    if (use_ws) return gan_reduce_slices(a.ws, a.dw, L, (int)(grid * C::WR), a.fu.gain, st);
     return GAN_OK;
 }
 
@@ -239,12 +277,13 @@ int pick_cout_w(const ThinWArgs& a, int ks, int64_t wsf, int64_t* need, hipStrea
 // need != nullptr: query only -- *need = workspace floats the launch would like (0 if not eligible).
 int gan_conv2d_wgrad_thin(const void* x, const void* gy, float* dw, const float* in_scale, int N, int H, int W,
                           int Cin, int up2, int Ho, int Wo, int Cout, int kh, int kw, int py, int px, float* ws,
-                          int64_t ws_floats, int64_t* need, hipStream_t st) {
+                          int64_t ws_floats, int64_t* need, const WgradFuse& fu, hipStream_t st) {
     if (need) *need = 0;
     if (kh != kw || (kh != 1 && kh != 3)) return 0;
     if (py != (kh - 1) / 2 || px != py) return 0;
     if (Cin > 64 || Cout > 64 || (Cin & 7) || (Cout & 7) || Wo < 32 || Ho < 8) return 0;
     ThinWArgs a;
+    a.fu = fu;
     a.x = x; a.gy = gy; a.dw = dw; a.in_scale = in_scale;
     a.N = N; a.H = H; a.W = W; a.Hl = up2 ? 2 * H : H; a.Wl = up2 ? 2 * W : W; a.up2 = up2;
     a.Ho = Ho; a.Wo = Wo; a.Cin = Cin; a.Cout = Cout; a.py = py; a.px = px;

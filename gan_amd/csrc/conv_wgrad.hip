@@ -26,6 +26,7 @@ struct WgradArgs {
     int ci_tiles;
     int64_t M;
     int64_t pix_per_split;
+    WgradFuse fu;
 };
 
 template <typename T>
@@ -127,32 +128,32 @@ __global__ void __launch_bounds__(256) conv_wgrad_k(const WgradArgs p) {
     for (int64_t m0 = m_begin; m0 < m_end; m0 += PIX) {
         const int64_t m = m0 + row;
         const bool in_range = m < m_end;
-        // ---- gy tile ------------------------------------------------------------------
+        const int64_t mm = in_range ? m : 0;
+        const int n = (int)(mm / HoWo);
+        const int rem = (int)(mm - (int64_t)n * HoWo);
+        const int oy = rem / p.Wo;
+        const int ox = rem - oy * p.Wo;
+        // ---- gy tile (gy_up2: gy is stored at half resolution) ---------------------------
         uint4 a_reg[NA];
+        {
+            const int gsh = p.fu.gy_up2;
+            const int64_t gbase = (((int64_t)n * (p.Ho >> gsh) + (oy >> gsh)) * (p.Wo >> gsh) + (ox >> gsh)) * p.Cout + co0;
 #pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            const int c = half + 2 * i;
-            a_reg[i] = in_range ? *reinterpret_cast<const uint4*>(gy + m * p.Cout + co0 + c * EPC) : make_uint4(0, 0, 0, 0);
+            for (int i = 0; i < NA; ++i)
+                a_reg[i] = ld16_or_zero(gy, (gbase + (half + 2 * i) * EPC) * (int64_t)sizeof(T), in_range);
         }
         // ---- shifted input tile -------------------------------------------------------
         uint4 b_reg[NB];
         {
-            const int64_t mm = in_range ? m : 0;
-            const int n = (int)(mm / HoWo);
-            const int rem = (int)(mm - (int64_t)n * HoWo);
-            const int oy = rem / p.Wo;
-            const int ox = rem - oy * p.Wo;
             const int iy = oy + dy, ix = ox + dx;
             const bool ok = in_range && (unsigned)iy < (unsigned)p.Hl && (unsigned)ix < (unsigned)p.Wl;
             const int64_t base = (((int64_t)n * p.H + (iy >> p.up2)) * p.W + (ix >> p.up2)) * p.Cin + ci0;
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
                 const int c = half + 2 * i;
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (ok) {
-                    v = *reinterpret_cast<const uint4*>(x + base + c * EPC);
-                    if (p.in_scale) v = wscale_chunk(v, p.in_scale + (int64_t)n * p.Cin + ci0 + c * EPC, T());
-                }
+                uint4 v = ld16_or_zero(x, (base + c * EPC) * (int64_t)sizeof(T), ok);
+                if (p.fu.x_slope != 1.f) v = lrelu_chunk(v, p.fu.x_slope, T());
+                if (p.in_scale) v = wscale_chunk(v, p.in_scale + (int64_t)n * p.Cin + ci0 + c * EPC, T());
                 b_reg[i] = v;
             }
         }
@@ -185,7 +186,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_k(const WgradArgs p) {
             for (int r = 0; r < 4; ++r) {
                 const int co = co0 + i * 16 + (lane >> 4) * 4 + r;
                 const int ci = ci0 + j * 16 + (lane & 15);
-                atomicAdd(dw + (int64_t)co * p.Cin + ci, acc[i][j][r]);
+                atomicAdd(dw + (int64_t)co * p.Cin + ci, acc[i][j][r] * p.fu.gain);
             }
 }
 
@@ -239,14 +240,15 @@ extern "C" int64_t gan_conv2d_wgrad_workspace(int N, int H, int W, int Cin, int 
     if (dtype != GAN_BF16 || N <= 0) return 0;
     int64_t need = 0;
     gan_conv2d_wgrad_thin(nullptr, nullptr, nullptr, nullptr, N, H, W, Cin, up2, Ho, Wo, Cout, kh, kw, py, px, nullptr, 0,
-                          &need, nullptr);
+                          &need, WgradFuse{1.f, 0, 1.f}, nullptr);
     if (need > 0) return need;
     return gan_wgrad_tiled_workspace(N, Ho, Wo, Cin, Cout, kh, kw, py, px);
 }
 
 extern "C" int gan_conv2d_wgrad(const void* x, const void* gy, float* dw, const float* in_scale, int N, int H, int W,
                                 int Cin, int up2, int Ho, int Wo, int Cout, int kh, int kw, int py, int px,
-                                float* workspace, int64_t workspace_floats, int dtype, gan_stream_t stream) {
+                                float* workspace, int64_t workspace_floats, float x_slope, int gy_up2, float gain,
+                                int dtype, gan_stream_t stream) {
     GAN_CHECK_ARG(dw && (N == 0 || (x && gy)), "conv2d_wgrad: null pointer");
     GAN_CHECK_ARG(dtype == GAN_F32 || dtype == GAN_BF16, "conv2d_wgrad: bad dtype %d", dtype);
     GAN_CHECK_ARG(N >= 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Ho > 0 && Wo > 0, "conv2d_wgrad: bad shape");
@@ -260,6 +262,8 @@ extern "C" int gan_conv2d_wgrad(const void* x, const void* gy, float* dw, const 
                   "conv2d_wgrad: output %dx%d does not match input %dx%d, kernel %dx%d, pad %d,%d", Ho, Wo, Hl, Wl,
                   kh, kw, py, px);
     GAN_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)gy % 16) == 0, "conv2d_wgrad: x and gy must be 16-byte aligned");
+    GAN_CHECK_ARG(gy_up2 == 0 || (gy_up2 == 1 && Ho % 2 == 0 && Wo % 2 == 0), "conv2d_wgrad: gy_up2 needs an even %dx%d output", Ho, Wo);
+    const WgradFuse fu{x_slope, gy_up2, gain};
     hipStream_t st = (hipStream_t)stream;
     const size_t bytes = sizeof(float) * (size_t)kh * kw * Cout * Cin;
     if (hipMemsetAsync(dw, 0, bytes, st) != hipSuccess) {
@@ -269,13 +273,14 @@ extern "C" int gan_conv2d_wgrad(const void* x, const void* gy, float* dw, const 
     if (N == 0) return GAN_OK;
     if (dtype == GAN_BF16) {
         int rc = gan_conv2d_wgrad_thin(x, gy, dw, in_scale, N, H, W, Cin, up2, Ho, Wo, Cout, kh, kw, py, px, workspace,
-                                       workspace_floats, nullptr, st);
+                                       workspace_floats, nullptr, fu, st);
         if (rc != 0) return rc < 0 ? rc : GAN_OK;
         rc = gan_conv2d_wgrad_tiled(x, gy, dw, in_scale, N, H, W, Cin, up2, Ho, Wo, Cout, kh, kw, py, px, workspace,
-                                    workspace_floats, st);
+                                    workspace_floats, fu, st);
         if (rc != 0) return rc < 0 ? rc : GAN_OK;
     }
     WgradArgs a;
+    a.fu = fu;
     a.x = x; a.gy = gy; a.dw = dw; a.in_scale = in_scale;
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Hl = Hl; a.Wl = Wl; a.up2 = up2;
     a.Ho = Ho; a.Wo = Wo; a.Cout = Cout; a.kh = kh; a.kw = kw; a.py = py; a.px = px;

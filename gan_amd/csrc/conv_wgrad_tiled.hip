@@ -26,6 +26,7 @@ struct TWArgs {
     int N, H, W, Hl, Wl, up2, Ho, Wo, Cin, Cout, py, px;
     int tiles_x, tiles_y;           // per image (NB == 1)
     int ntiles, S, ci_tiles;
+    WgradFuse fu;
 };
 
 __device__ __forceinline__ uint4 tmod_chunk(uint4 raw, const float* s) {
@@ -148,8 +149,8 @@ __global__ void __launch_bounds__(320) conv_wgrad_tiled_k(const TWArgs p) {
                         const int xq = (isx ? ox0 - p.px : ox0) + ((pk >> 8) & 0xff);
                         const bool ok = ((pk >> 25) & 1) && nn < p.N && (unsigned)y < (unsigned)(isx ? p.Hl : p.Ho) &&
                                         (unsigned)xq < (unsigned)(isx ? p.Wl : p.Wo);
-                        const int sh = isx ? p.up2 : 0;
-                        const int off = ((nn * (isx ? p.H : p.Ho) + (y >> sh)) * (isx ? p.W : p.Wo) + (xq >> sh)) * (isx ? p.Cin : p.Cout) +
+                        const int sh = isx ? p.up2 : p.fu.gy_up2;  // gy_up2: gy is stored at half resolution
+                        const int off = ((nn * (isx ? p.H : p.Ho >> sh) + (y >> sh)) * (isx ? p.W : p.Wo >> sh) + (xq >> sh)) * (isx ? p.Cin : p.Cout) +
                                         (isx ? cix : cog);
                         v[k] = ld16_or_zero(isx ? (const void*)x : (const void*)gy, (int64_t)off * 2, ok);
                         if (MOD) {
@@ -166,6 +167,7 @@ __global__ void __launch_bounds__(320) conv_wgrad_tiled_k(const TWArgs p) {
                 for (int k = 0; k < U; ++k) {
                     if (b0 + k < NSLOT) {
                         uint4 u = v[k];
+                        if (p.fu.x_slope != 1.f) u = lrelu_chunk(u, ((packed[b0 + k] >> 24) & 1) ? p.fu.x_slope : 1.f, bf16());
                         if (MOD) {
                             bf16x8 h = *reinterpret_cast<bf16x8*>(&u);
                             h[0] = (bf16)((float)h[0] * s0[k].x); h[1] = (bf16)((float)h[1] * s0[k].y);
@@ -258,7 +260,7 @@ __global__ void __launch_bounds__(320) conv_wgrad_tiled_k(const TWArgs p) {
 
 // out[e] += sum over a chunk of 32 slices of ws[s][e]   (out zeroed by the caller; few adders per address)
 __global__ void __launch_bounds__(256) reduce_slices_k(const float* __restrict__ ws, float* __restrict__ out, int64_t L,
-                                                       int S) {
+                                                       int S, float gain) {
     const int64_t e4 = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (e4 * 4 >= L) return;
     const int s0 = blockIdx.y * 32;
@@ -270,6 +272,7 @@ __global__ void __launch_bounds__(256) reduce_slices_k(const float* __restrict__
         const float4 v = *reinterpret_cast<const float4*>(src + (int64_t)s * L);
         a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
     }
+    a.x *= gain; a.y *= gain; a.z *= gain; a.w *= gain;
     float* o = out + e4 * 4;
     if (gridDim.y == 1) {
         *reinterpret_cast<float4*>(o) = a;
@@ -332,11 +335,12 @@ int64_t gan_wgrad_tiled_workspace(int N, int Ho, int Wo, int Cin, int Cout, int 
 // 1 = served (dw zeroed by the caller), 0 = not eligible / workspace too small, < 0 = error.
 int gan_conv2d_wgrad_tiled(const void* x, const void* gy, float* dw, const float* in_scale, int N, int H, int W,
                            int Cin, int up2, int Ho, int Wo, int Cout, int kh, int kw, int py, int px, float* ws,
-                           int64_t ws_floats, hipStream_t st) {
+                           int64_t ws_floats, const WgradFuse& fu, hipStream_t st) {
     const int64_t need = gan_wgrad_tiled_workspace(N, Ho, Wo, Cin, Cout, kh, kw, py, px);
     if (need == 0 || ws == nullptr || ws_floats < need || (((uintptr_t)ws) & 15)) return 0;
     const TiledPlan pl = plan_tiled(N, Ho, Wo, Cin, Cout, kh);
     TWArgs a;
+    a.fu = fu;
     a.x = x; a.gy = gy; a.ws = ws; a.in_scale = in_scale;
     a.N = N; a.H = H; a.W = W; a.Hl = up2 ? 2 * H : H; a.Wl = up2 ? 2 * W : W; a.up2 = up2;
     a.Ho = Ho; a.Wo = Wo; a.Cin = Cin; a.Cout = Cout; a.py = py; a.px = px;
@@ -366,13 +370,13 @@ int gan_conv2d_wgrad_tiled(const void* x, const void* gy, float* dw, const float
         gan_set_error("conv2d_wgrad(tiled): launch failed: %s", hipGetErrorString(e));
         return GAN_ERR_LAUNCH;
     }
-    const int rc = gan_reduce_slices(ws, dw, (int64_t)kh * kw * Cout * Cin, pl.S, st);
+    const int rc = gan_reduce_slices(ws, dw, (int64_t)kh * kw * Cout * Cin, pl.S, fu.gain, st);
     return rc == GAN_OK ? 1 : rc;
 }
 
-int gan_reduce_slices(const float* ws, float* out, int64_t L, int S, hipStream_t st) {
+int gan_reduce_slices(const float* ws, float* out, int64_t L, int S, float gain, hipStream_t st) {
     const int64_t blocks = ceil_div64(ceil_div64(L, 4), 256);
-    hipLaunchKernelGGL(reduce_slices_k, dim3((unsigned)blocks, (unsigned)((S + 31) / 32)), dim3(256), 0, st, ws, out, L, S);
+    hipLaunchKernelGGL(reduce_slices_k, dim3((unsigned)blocks, (unsigned)((S + 31) / 32)), dim3(256), 0, st, ws, out, L, S, gain);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         gan_set_error("reduce_slices: launch failed: %s", hipGetErrorString(e));

@@ -299,9 +299,16 @@ def raw_conv2d(
     noise_scale: Optional[Tensor] = None,
     slope: float = 1.0,
     transposed: bool = False,
+    in_slope: float = 1.0,
+    pool: bool = False,
+    aux: Optional[Tensor] = None,
+    aux_slope: float = 1.0,
+    gain: float = 1.0,
 ) -> Tensor:
     """Stride-1 correlation of channels-last x with weight (Cout, Cin, kh, kw) + fused prologue/epilogue.
-    `transposed`: correlate with the flipped, channel-swapped weights instead (weight is (Cin, Cout, kh, kw))."""
+    `transposed`: correlate with the flipped, channel-swapped weights instead (weight is (Cin, Cout, kh, kw)).
+    in_slope / pool / aux / gain: the fused LeakyReLU-before, AvgPool2d(2)-after, mask-after and scalar stages
+    (include/gan_amd.h: gan_conv2d_fwd)."""
     require_gpu(x, weight, in_scale, out_scale, bias, noise, noise_scale)
     lib = _lib.load()
     x = _pad_channels(x.detach(), 8)
@@ -325,34 +332,50 @@ def raw_conv2d(
         out_scale32 = out_scale32.reshape(1, cout).expand(n, cout).contiguous()
     bias32, _ = _side(bias, 1, cout, "conv2d bias")
     ns32, _ = _side(noise_scale, 1, cout, "conv2d noise scale")
+    if pool and (ho % 2 or wo % 2):
+        raise _lib.GanAmdError(f"conv2d: pooling needs an even output, got {ho}x{wo}")
+    hy, wy = (ho // 2, wo // 2) if pool else (ho, wo)
     if noise is not None:
-        noise = noise.detach().to(x.dtype).reshape(n, ho * wo).contiguous()
-    y = _empty_like_cl(x, (n, cout, ho, wo))
+        noise = noise.detach().to(x.dtype).reshape(n, hy * wy).contiguous()
+    if aux is not None:
+        if tuple(aux.shape) != (n, cout, hy, wy):
+            raise _lib.GanAmdError(f"conv2d: aux shape {tuple(aux.shape)} != output shape {(n, cout, hy, wy)}")
+        aux = as_cl(aux.detach().to(x.dtype))
+    y = _empty_like_cl(x, (n, cout, hy, wy))
     check(
         _run(
-            "conv2d_fwd", 2.0 * n * ho * wo * cout * cin * kh * kw, _nbytes(x, y, wt, noise),
+            "conv2d_fwd", 2.0 * n * ho * wo * cout * cin * kh * kw, _nbytes(x, y, wt, noise, aux),
             lambda: lib.gan_conv2d_fwd(
                 ptr(x), ptr(wt), ptr(y), ptr(in_scale), ptr(out_scale32), ptr(bias32), ptr(noise), ptr(ns32), float(slope),
-                n, h, w, cin_p, int(up2), ho, wo, cout, kh, kw, py, px, kpad, dtype_code(x), stream_of(x),
+                n, h, w, cin_p, int(up2), ho, wo, cout, kh, kw, py, px, kpad,
+                float(in_slope), int(pool), ptr(aux), float(aux_slope), float(gain), dtype_code(x), stream_of(x),
             ),
-            (n, cin, ho, wo, cout, kh, int(up2)),
+            (n, cin, ho, wo, cout, kh, int(up2), int(pool)),
         ),
         "gan_conv2d_fwd",
     )
     return y
 
 
-def raw_conv2d_dgrad(gy: Tensor, weight: Tensor, py: int, px: int, *, out_scale: Optional[Tensor] = None) -> Tensor:
+def raw_conv2d_dgrad(
+    gy: Tensor, weight: Tensor, py: int, px: int, *, out_scale: Optional[Tensor] = None,
+    pooled: bool = False, aux: Optional[Tensor] = None, aux_slope: float = 1.0,
+) -> Tensor:
     """Input gradient of a stride-1 correlation = correlation of gy with the transposed, flipped
-    weights and padding k-1-p.  Output spatial size is the forward input size."""
+    weights and padding k-1-p.  Output spatial size is the forward input size.
+    pooled: gy is the gradient of the 2x2-average-pooled output (nearest-2x gather, gain 1/4);
+    aux: multiply by the leaky-ReLU mask of aux (the activation that preceded the convolution)."""
     cout, cin, kh, kw = weight.shape
-    return raw_conv2d(gy, weight, kh - 1 - py, kw - 1 - px, out_scale=out_scale, transposed=True)
+    return raw_conv2d(gy, weight, kh - 1 - py, kw - 1 - px, out_scale=out_scale, transposed=True,
+                      up2=pooled, gain=0.25 if pooled else 1.0, aux=aux, aux_slope=aux_slope)
 
 
 def raw_conv2d_wgrad(
-    x: Tensor, gy: Tensor, kh: int, kw: int, py: int, px: int, *, up2: bool = False, in_scale: Optional[Tensor] = None
+    x: Tensor, gy: Tensor, kh: int, kw: int, py: int, px: int, *, up2: bool = False, in_scale: Optional[Tensor] = None,
+    x_slope: float = 1.0, pooled: bool = False,
 ) -> Tensor:
-    """fp32 (Cout, Cin, kh, kw)."""
+    """fp32 (Cout, Cin, kh, kw).  x_slope: x goes through leaky-ReLU first; pooled: gy is the gradient of the
+    2x2-average-pooled output (half resolution)."""
     require_gpu(x, gy, in_scale)
     lib = _lib.load()
     cin, cout = x.shape[1], gy.shape[1]
@@ -361,6 +384,8 @@ def raw_conv2d_wgrad(
     gy = _pad_channels(gy, 16)
     n, cin_p, h, w = x.shape
     cout_p, ho, wo = gy.shape[1], gy.shape[2], gy.shape[3]
+    if pooled:
+        ho, wo = 2 * ho, 2 * wo
     if in_scale is not None:
         in_scale = _f32(in_scale).reshape(n, cin)
         if cin_p != cin:
@@ -375,9 +400,9 @@ def raw_conv2d_wgrad(
             "conv2d_wgrad", 2.0 * n * ho * wo * cout * cin * kh * kw, _nbytes(x, gy, dw),
             lambda: lib.gan_conv2d_wgrad(
                 ptr(x), ptr(gy), ptr(dw), ptr(in_scale), n, h, w, cin_p, int(up2), ho, wo, cout_p, kh, kw, py, px,
-                ptr(ws), ws_floats, dtype_code(x), stream_of(x)
+                ptr(ws), ws_floats, float(x_slope), int(pooled), 0.25 if pooled else 1.0, dtype_code(x), stream_of(x)
             ),
-            (n, cin, ho, wo, cout, kh, int(up2)),
+            (n, cin, ho, wo, cout, kh, int(up2), int(pooled)),
         ),
         "gan_conv2d_wgrad",
     )
@@ -546,59 +571,72 @@ class PixelDotFn(Function):
 
 
 class Conv2dFn(Function):
-    """Stride-1 correlation y = conv(x, W) with zero padding (py, px); no bias (biases ride in the
-    fused epilogues).  Reference arithmetic: F.conv2d as used by nn.Conv2d (progressive_gan.py:45-50)
-    and by batched_conv2d (stylegan2.py:18,36)."""
+    """y = AvgPool2?( conv( leaky_relu?(x), W ) ): stride-1 correlation with zero padding (py, px), no bias
+    (biases ride in the fused epilogues).  The activation BEFORE the convolution (in_slope != 1) and the 2x2
+    average pooling AFTER it are fused into the kernel: the discriminator block's LeakyReLU -> Conv2d and
+    LeakyReLU -> Conv2d -> AvgPool2d chains (progressive_gan.py:45-50) are one launch each.
+    Reference arithmetic: F.conv2d as used by nn.Conv2d and by batched_conv2d (stylegan2.py:18,36).
+
+    Conv2dFn / Conv2dDgradFn / Conv2dWgradFn are closed under differentiation: for fixed activation masks
+    the map is bilinear in (x, W), and leaky-ReLU has no second derivative."""
 
     @staticmethod
-    def forward(ctx, x, weight, py, px):
+    def forward(ctx, x, weight, py, px, in_slope=1.0, pool=False):
         ctx.save_for_backward(x, weight)
-        ctx.pad = (py, px)
-        return raw_conv2d(x, weight, py, px)
+        ctx.cfg = (py, px, in_slope, pool)
+        return raw_conv2d(x, weight, py, px, in_slope=in_slope, pool=pool)
 
     @staticmethod
     def backward(ctx, gy):
         x, weight = ctx.saved_tensors
-        py, px = ctx.pad
-        gx = Conv2dDgradFn.apply(gy, weight, py, px) if _need(ctx, 0) else None
-        gw = Conv2dWgradFn.apply(x, gy, weight.shape[2], weight.shape[3], py, px).to(weight.dtype) if _need(ctx, 1) else None
-        return gx, gw, None, None
+        py, px, in_slope, pool = ctx.cfg
+        xaux = x if in_slope != 1.0 else None
+        gx = Conv2dDgradFn.apply(gy, weight, py, px, xaux, in_slope, pool) if _need(ctx, 0) else None
+        gw = None
+        if _need(ctx, 1):
+            gw = Conv2dWgradFn.apply(x, gy, weight.shape[2], weight.shape[3], py, px, in_slope, pool).to(weight.dtype)
+        return gx, gw, None, None, None, None
 
 
 class Conv2dDgradFn(Function):
-    """gx = dgrad(gy, W): bilinear in (gy, W)."""
+    """gx = m(xaux) * dgrad( PoolAdj?(gy), W ): the adjoint of Conv2dFn in x.  PoolAdj (nearest-2x gather,
+    gain 1/4) and the mask of the activation that preceded the convolution are fused into the kernel."""
 
     @staticmethod
-    def forward(ctx, gy, weight, py, px):
-        ctx.save_for_backward(gy, weight)
-        ctx.pad = (py, px)
-        return raw_conv2d_dgrad(gy, weight, py, px)
+    def forward(ctx, gy, weight, py, px, xaux=None, slope=1.0, pool=False):
+        ctx.save_for_backward(gy, weight, xaux)
+        ctx.cfg = (py, px, slope, pool)
+        return raw_conv2d_dgrad(gy, weight, py, px, pooled=pool, aux=xaux, aux_slope=slope)
 
     @staticmethod
     def backward(ctx, ggx):
-        gy, weight = ctx.saved_tensors
-        py, px = ctx.pad
-        g_gy = Conv2dFn.apply(ggx, weight, py, px).to(gy.dtype) if _need(ctx, 0) else None
-        g_w = Conv2dWgradFn.apply(ggx, gy, weight.shape[2], weight.shape[3], py, px).to(weight.dtype) if _need(ctx, 1) else None
-        return g_gy, g_w, None, None
+        gy, weight, xaux = ctx.saved_tensors
+        py, px, slope, pool = ctx.cfg
+        z = MaskMulFn.apply(ggx, xaux, slope) if xaux is not None else ggx
+        g_gy = Conv2dFn.apply(z, weight, py, px, 1.0, pool).to(gy.dtype) if _need(ctx, 0) else None
+        g_w = None
+        if _need(ctx, 1):
+            g_w = Conv2dWgradFn.apply(z, gy, weight.shape[2], weight.shape[3], py, px, 1.0, pool).to(weight.dtype)
+        return g_gy, g_w, None, None, None, None, None
 
 
 class Conv2dWgradFn(Function):
-    """gW = wgrad(x, gy) in fp32: bilinear in (x, gy)."""
+    """gW = wgrad( leaky_relu?(x), PoolAdj?(gy) ) in fp32: the adjoint of Conv2dFn in W."""
 
     @staticmethod
-    def forward(ctx, x, gy, kh, kw, py, px):
+    def forward(ctx, x, gy, kh, kw, py, px, x_slope=1.0, pool=False):
         ctx.save_for_backward(x, gy)
-        ctx.cfg = (kh, kw, py, px)
-        return raw_conv2d_wgrad(x, gy, kh, kw, py, px)
+        ctx.cfg = (kh, kw, py, px, x_slope, pool)
+        return raw_conv2d_wgrad(x, gy, kh, kw, py, px, x_slope=x_slope, pooled=pool)
 
     @staticmethod
     def backward(ctx, ggw):
         x, gy = ctx.saved_tensors
-        kh, kw, py, px = ctx.cfg
-        g_x = Conv2dDgradFn.apply(gy, ggw, py, px).to(x.dtype) if _need(ctx, 0) else None
-        g_gy = Conv2dFn.apply(x, ggw, py, px).to(gy.dtype) if _need(ctx, 1) else None
-        return g_x, g_gy, None, None, None, None
+        kh, kw, py, px, x_slope, pool = ctx.cfg
+        xaux = x if x_slope != 1.0 else None
+        g_x = Conv2dDgradFn.apply(gy, ggw, py, px, xaux, x_slope, pool).to(x.dtype) if _need(ctx, 0) else None
+        g_gy = Conv2dFn.apply(x, ggw, py, px, x_slope, pool).to(gy.dtype) if _need(ctx, 1) else None
+        return g_x, g_gy, None, None, None, None, None, None
 
 
 class AffineActFn(Function):
@@ -677,32 +715,36 @@ def act_dtype(x: Tensor) -> torch.dtype:
 
 
 class ConvBiasActFn(Function):
-    """lrelu_slope(conv(x, W) + b) with bias and activation applied to the MFMA accumulators (one
-    launch, one store).  Replaces nn.Conv2d -> nn.LeakyReLU (progressive_gan.py:45-46,72-73).
+    """lrelu_slope(conv(lrelu_in(x), W) + b): the activation before the convolution applied as the input is
+    staged, bias and the activation after it applied to the MFMA accumulators (one launch, one store).
+    Replaces nn.LeakyReLU -> nn.Conv2d [-> nn.LeakyReLU] (progressive_gan.py:45-48,72-73).
     Backward = mask_mul -> dgrad / wgrad / channel sum, all differentiable again."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, pad, slope):
-        y = raw_conv2d(x, weight, pad, pad, bias=bias, slope=slope)
-        ctx.save_for_backward(x, weight, bias, y)
-        ctx.pad, ctx.slope = pad, slope
+    def forward(ctx, x, weight, bias, pad, slope, in_slope=1.0):
+        y = raw_conv2d(x, weight, pad, pad, bias=bias, slope=slope, in_slope=in_slope)
+        ctx.save_for_backward(x, weight, bias, y if slope != 1.0 else None)
+        ctx.cfg = (pad, slope, in_slope)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         x, weight, bias, y = ctx.saved_tensors
-        pad, slope = ctx.pad, ctx.slope
+        pad, slope, in_slope = ctx.cfg
         gz = MaskMulFn.apply(gy, y, slope) if slope != 1.0 else gy
-        gx = Conv2dDgradFn.apply(gz, weight, pad, pad) if _need(ctx, 0) else None
-        gw = Conv2dWgradFn.apply(x, gz, weight.shape[2], weight.shape[3], pad, pad).to(weight.dtype) if _need(ctx, 1) else None
+        xaux = x if in_slope != 1.0 else None
+        gx = Conv2dDgradFn.apply(gz, weight, pad, pad, xaux, in_slope, False) if _need(ctx, 0) else None
+        gw = None
+        if _need(ctx, 1):
+            gw = Conv2dWgradFn.apply(x, gz, weight.shape[2], weight.shape[3], pad, pad, in_slope, False).to(weight.dtype)
         gb = None
         if bias is not None and _need(ctx, 2):
             gb = ChanSumFn.apply(gz, False).reshape(bias.shape).to(bias.dtype)
-        return gx, gw, gb, None, None
+        return gx, gw, gb, None, None, None
 
 
-def conv_bias_act(x: Tensor, weight: Tensor, bias: Optional[Tensor], padding: int, slope: float = 1.0) -> Tensor:
-    return ConvBiasActFn.apply(x, weight, bias, padding, slope)
+def conv_bias_act(x: Tensor, weight: Tensor, bias: Optional[Tensor], padding: int, slope: float = 1.0, in_slope: float = 1.0) -> Tensor:
+    return ConvBiasActFn.apply(x, weight, bias, padding, slope, in_slope)
 
 
 def minibatch_stddev_stat(x: Tensor, group: int) -> Tensor:

@@ -35,6 +35,8 @@ class Conv2d(nn.Conv2d):
     def forward(self, x: Tensor) -> Tensor:
         self._check()
         x = to_act(x)
+        if self.bias is not None and self.padding[0] == self.padding[1]:
+            return GF.conv_bias_act(x, self.weight, self.bias, self.padding[0])  # bias on the accumulators
         y = GF.Conv2dFn.apply(x, self.weight, self.padding[0], self.padding[1])
         if self.bias is not None:
             y = GF.affine_act(y, b=self.bias)

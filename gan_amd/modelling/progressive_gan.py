@@ -5,9 +5,12 @@ child-module layout and state_dict keys.  Every convolution, leaky-ReLU, pooling
 on the HIP kernels through Functions whose backward is again made of those kernels, so the R1 /
 WGAN-GP double backward (losses.py:89-103) never differentiates through PyTorch ops' autograd.
 
-Fusions per block (progressive_gan.py:43-54):  bias + LeakyReLU ride behind the first conv in one
-pass; conv biases that precede AvgPool2d are added after it (avg_pool(z + b) = avg_pool(z) + b) and
-folded, together with the shortcut's bias and the per-channel `scale`, into the single residual pass
+Fusions per block (progressive_gan.py:43-54):  each LeakyReLU is applied by the convolution that
+consumes it while it stages its input, AvgPool2d(2) is applied to the MFMA accumulators of the
+convolution that precedes it (the shortcut's pool -> 1x1 conv runs as conv -> pool, the same linear
+map), and the adjoints of both ride in the input-/weight-gradient kernels; conv biases that precede
+AvgPool2d are added after it (avg_pool(z + b) = avg_pool(z) + b) and folded, together with the
+shortcut's bias and the per-channel `scale`, into the single residual pass
     out = shortcut_conv + pooled * scale + (b_short + b2 * scale).
 LeakyReLU is applied out of place (the shipped inplace=True breaks autograd).
 """
@@ -56,11 +59,11 @@ class ProgressiveGanDiscriminatorBlock(nn.Module):
         x = to_act(x)
         act0, conv1, act1, conv2, _ = self.layers
         conv_s = self.shortcut[1]
-        h = GF.leaky_relu(x, act0.negative_slope)
-        h = GF.conv_bias_act(h, conv1.weight, conv1.bias, conv1.padding[0], act1.negative_slope)
-        h = GF.Conv2dFn.apply(h, conv2.weight, conv2.padding[0], conv2.padding[1])
-        h = GF.avg_pool2(h)
-        s = GF.Conv2dFn.apply(GF.avg_pool2(x), conv_s.weight, 0, 0)
+        # act -> conv1 (+bias) | act -> conv2 -> pool | conv_s -> pool  (= pool -> conv_s: both are linear
+        # and a 1x1 convolution commutes with the pooling): three launches, no elementwise pass
+        h = GF.conv_bias_act(x, conv1.weight, conv1.bias, conv1.padding[0], 1.0, act0.negative_slope)
+        h = GF.Conv2dFn.apply(h, conv2.weight, conv2.padding[0], conv2.padding[1], act1.negative_slope, True)
+        s = GF.Conv2dFn.apply(x, conv_s.weight, 0, 0, 1.0, True)
         scale = self.scale.reshape(-1)
         bias = conv_s.bias + conv2.bias * scale  # (Cout,) -- three tiny vectors
         return GF.affine_act(h, a=scale, b=bias, r=s)

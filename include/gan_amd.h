@@ -90,10 +90,21 @@ int gan_chan_dot(const void* A, const void* B, int b_mode, const void* ymask, fl
  * Stride 1.  x: [N][H][W][Cin] with Cin % 8 == 0; wt: [Cout][Kpad] in the activation dtype,
  * K index = tap*Cin + ci, zero-padded to Kpad (multiple of 32, >= kh*kw*Cin);
  * y: [N][Ho][Wo][Cout]; in_scale [N][Cin], out_scale [N][Cout], bias/noise_scale [Cout] fp32 or NULL;
- * noise [N][Ho*Wo] in the activation dtype or NULL; slope = 1 for no activation. */
+ * noise [N][Ho*Wo] in the activation dtype or NULL; slope = 1 for no activation.
+ *
+ * Stages of the discriminator block fused around the GEMM (progressive_gan.py:45-52: LeakyReLU -> Conv2d
+ * [-> AvgPool2d], and the adjoints of those in the backward pass), so they cost no pass over HBM:
+ *   in_slope != 1 : X = leaky_relu(x, in_slope) applied as the input is staged (before in_scale);
+ *   pool = 1      : the convolution result is 2x2 average pooled (Ho, Wo even) BEFORE out_scale / bias /
+ *                   noise / act; y, noise and aux are then at (Ho/2, Wo/2).  Ho, Wo stay the un-pooled size;
+ *   aux != NULL   : y *= m(aux), m(v) = v > 0 ? 1 : aux_slope, aux shaped like y (the leaky-ReLU derivative
+ *                   mask that follows an input gradient);
+ *   gain          : scalar factor on the accumulated sum (0.25 for the adjoint of the pooling, whose
+ *                   nearest-neighbour upsampling is the up2 gather).  Pass 1, 0, NULL, 1, 1 for none. */
 int gan_conv2d_fwd(const void* x, const void* wt, void* y, const float* in_scale, const float* out_scale,
                    const float* bias, const void* noise, const float* noise_scale, float slope, int N, int H, int W,
-                   int Cin, int up2, int Ho, int Wo, int Cout, int kh, int kw, int py, int px, int Kpad, int dtype,
+                   int Cin, int up2, int Ho, int Wo, int Cout, int kh, int kw, int py, int px, int Kpad,
+                   float in_slope, int pool, const void* aux, float aux_slope, float gain, int dtype,
                    gan_stream_t stream);
 
 /* Weight gradient (autograd of the convolutions above):
@@ -102,12 +113,17 @@ int gan_conv2d_fwd(const void* x, const void* wt, void* y, const float* in_scale
  * The reduction over pixels is split over workgroups; with a workspace of at least
  * gan_conv2d_wgrad_workspace(...) floats (16-byte aligned, contents undefined on entry and exit) the
  * partial tiles are written with plain stores and folded by a second kernel, otherwise (workspace NULL)
- * they are accumulated into dw with fp32 atomics.  The library never allocates: the caller owns it. */
+ * they are accumulated into dw with fp32 atomics.  The library never allocates: the caller owns it.
+ * Fused stages (the weight gradient of the LeakyReLU -> Conv2d -> AvgPool2d chain, progressive_gan.py:45-50):
+ *   x_slope != 1 : X = leaky_relu(x, x_slope) as it is staged (before in_scale);
+ *   gy_up2 = 1   : gy is [N][Ho/2][Wo/2][Cout] and read through a nearest-neighbour 2x gather (the adjoint
+ *                  of the pooling, together with gain = 0.25);
+ *   gain         : scalar factor on dw.  Pass 1, 0, 1 for none. */
 int64_t gan_conv2d_wgrad_workspace(int N, int H, int W, int Cin, int up2, int Ho, int Wo, int Cout, int kh, int kw,
                                    int py, int px, int dtype);
 int gan_conv2d_wgrad(const void* x, const void* gy, float* dw, const float* in_scale, int N, int H, int W, int Cin,
                      int up2, int Ho, int Wo, int Cout, int kh, int kw, int py, int px, float* workspace,
-                     int64_t workspace_floats, int dtype, gan_stream_t stream);
+                     int64_t workspace_floats, float x_slope, int gy_up2, float gain, int dtype, gan_stream_t stream);
 
 /* ---- MinibatchStdDev ---------------------------------------------------------------------
  * replaces MinibatchStdDev.forward   modelling/progressive_gan.py:20-36

@@ -402,3 +402,86 @@ def test_conv2d_tiled_wgrad_kernel(dev, case):
     got = GF.raw_conv2d_wgrad(x.to(dev), gy.to(dev), k, k, pad, pad, up2=up2, in_scale=s.to(dev))
     assert got.shape == ref.shape and got.dtype == torch.float32
     assert rel_err(got, ref) < 1e-4, rel_err(got, ref)
+
+
+FUSED_CASES = [
+    # N, Cin, H, W, Cout, k   (even H, W): LeakyReLU -> conv -> AvgPool2d(2) as ONE launch, and its adjoints
+    (2, 16, 64, 64, 32, 3),  # thin forward / thin weight gradient
+    (2, 32, 40, 48, 64, 3),
+    (2, 16, 64, 64, 32, 1),
+    (2, 64, 32, 32, 16, 3),
+    (3, 8, 32, 64, 16, 1),
+    (4, 64, 64, 64, 128, 3),  # wide forward (quad-major rows), tiled weight gradient
+    (3, 128, 16, 16, 256, 3),
+    (5, 128, 8, 8, 128, 3),
+    (6, 32, 4, 4, 64, 3),
+    (2, 256, 8, 8, 512, 1),
+    (3, 24, 6, 10, 40, 3),  # generic kernels
+]
+
+
+@pytest.mark.parametrize("case", FUSED_CASES)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv2d_act_pool_fusion(dev, case, dtype):
+    """Conv2dFn(in_slope, pool) and the fused adjoints (mask epilogue, pooled-gy gathers) against
+    avg_pool2d(conv2d(leaky_relu(x))) differentiated by torch in fp64."""
+    import gan_amd.functional as GF
+
+    n, cin, h, w, cout, k = case
+    pad = (k - 1) // 2
+    torch.manual_seed(21)
+    x = torch.randn(n, cin, h, w).to(dtype)
+    wgt = torch.randn(cout, cin, k, k) / (cin * k * k) ** 0.5
+    w_in = wgt.to(dtype).float() if dtype == torch.bfloat16 else wgt
+    tol = TOL32 if dtype == torch.float32 else 6e-3
+    for in_slope, pool in ((0.2, True), (0.2, False), (1.0, True)):
+        x_ref = x.double().requires_grad_(True)
+        w_ref = w_in.double().requires_grad_(True)
+        a_ref = F.leaky_relu(x_ref, in_slope) if in_slope != 1.0 else x_ref
+        y_ref = F.conv2d(a_ref, w_ref, padding=pad)
+        if pool:
+            y_ref = F.avg_pool2d(y_ref, 2)
+        xg = x.to(dev).requires_grad_(True)
+        wg = wgt.to(dev).requires_grad_(True)
+        y = GF.Conv2dFn.apply(xg, wg, pad, pad, in_slope, pool)
+        assert y.shape == y_ref.shape and y.dtype == dtype
+        assert rel_err(y, y_ref) < tol, ("fwd", in_slope, pool, rel_err(y, y_ref))
+        cot = torch.randn(y_ref.shape).to(dtype)
+        gx_ref, gw_ref = torch.autograd.grad((y_ref * cot.double()).sum(), [x_ref, w_ref])
+        gx, gw = torch.autograd.grad((y * cot.to(dev)).sum(), [xg, wg])
+        assert rel_err(gx, gx_ref) < tol, ("dgrad", in_slope, pool, rel_err(gx, gx_ref))
+        assert rel_err(gw, gw_ref) < tol, ("wgrad", in_slope, pool, rel_err(gw, gw_ref))
+
+
+def test_conv2d_act_pool_second_order(dev):
+    """The fused triple stays closed under differentiation (R1 differentiates the D block twice)."""
+    import gan_amd.functional as GF
+
+    torch.manual_seed(22)
+    x = torch.randn(2, 16, 8, 8)
+    wgt = torch.randn(24, 16, 3, 3) / 12
+    b = torch.randn(24)
+    x_ref = x.double().requires_grad_(True)
+    w_ref = wgt.double().requires_grad_(True)
+    y_ref = F.avg_pool2d(F.conv2d(F.leaky_relu(x_ref, 0.2), w_ref, padding=1), 2)
+    gx_ref, gw_ref = torch.autograd.grad(y_ref.square().sum(), [x_ref, w_ref], create_graph=True)
+    hx_ref, hw_ref = torch.autograd.grad(gx_ref.square().sum() + gw_ref.square().sum(), [x_ref, w_ref])
+    xg = x.to(dev).requires_grad_(True)
+    wg = wgt.to(dev).requires_grad_(True)
+    y = GF.Conv2dFn.apply(xg, wg, 1, 1, 0.2, True)
+    gx, gw = torch.autograd.grad(y.square().sum(), [xg, wg], create_graph=True)
+    hx, hw = torch.autograd.grad(gx.square().sum() + gw.square().sum(), [xg, wg])
+    assert rel_err(gx, gx_ref) < TOL32 and rel_err(gw, gw_ref) < TOL32
+    assert rel_err(hx, hx_ref) < TOL32_2 and rel_err(hw, hw_ref) < TOL32_2
+    # conv_bias_act with the activation on both sides
+    x_ref = x.double().requires_grad_(True)
+    w_ref = wgt.double().requires_grad_(True)
+    y_ref = F.leaky_relu(F.conv2d(F.leaky_relu(x_ref, 0.2), w_ref, b.double(), padding=1), 0.1)
+    gx_ref, gw_ref = torch.autograd.grad(y_ref.square().sum(), [x_ref, w_ref], create_graph=True)
+    hx_ref, hw_ref = torch.autograd.grad(gx_ref.square().sum() + gw_ref.square().sum(), [x_ref, w_ref])
+    y = GF.conv_bias_act(xg, wg, b.to(dev), 1, 0.1, 0.2)
+    assert rel_err(y, y_ref) < TOL32
+    gx, gw = torch.autograd.grad(y.square().sum(), [xg, wg], create_graph=True)
+    hx, hw = torch.autograd.grad(gx.square().sum() + gw.square().sum(), [xg, wg])
+    assert rel_err(gx, gx_ref) < TOL32 and rel_err(gw, gw_ref) < TOL32
+    assert rel_err(hx, hx_ref) < TOL32_2 and rel_err(hw, hw_ref) < TOL32_2
