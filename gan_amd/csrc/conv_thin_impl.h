@@ -88,7 +88,7 @@ struct ThinCfg {
 // a branch: an if/else with different stores on its two sides makes hipcc forget how many memory
 // instructions are in flight (it then waits for all of them).
 template <int CIN, int COUT, int KS, int RPW, int MODE, bool VEC>
-__global__ void __launch_bounds__(256) conv_thin_k(const ThinArgs p) {
+__global__ void __launch_bounds__(256, 2) conv_thin_k(const ThinArgs p) {
     typedef ThinCfg<CIN, COUT, KS, RPW> C;
     constexpr int CP = C::CP, TH = C::TH, HWD = C::HWD, NPIX = C::NPIX, PLANE = C::PLANE;
     constexpr int NSTEP = C::NSTEP, KPAD = C::KPAD, FCO = C::FCO, FPX = C::FPX, NLD = C::NLD;

@@ -27,6 +27,7 @@ struct ThinWArgs {
     int N, H, W, Hl, Wl, up2, Ho, Wo, Cin, Cout, py, px;
     int tiles_x, tiles_y;
     float* ws;  // optional [gridDim.x * WR][taps][Cout][Cin] partial slices (plain stores) instead of atomics
+    unsigned x_bytes, g_bytes;  // < 2^31: 32-bit buffer offsets
     WgradFuse fu;
 };
 
@@ -68,7 +69,7 @@ struct ThinWCfg {
 };
 
 template <int CIN, int COUT, int KS, int TH, int WT>
-__global__ void __launch_bounds__(256) conv_thin_wgrad_k(const ThinWArgs p) {
+__global__ void __launch_bounds__(256, 2) conv_thin_wgrad_k(const ThinWArgs p) {
     typedef ThinWCfg<CIN, COUT, KS, TH, WT> C;
     constexpr int CGI = C::CGI, CGO = C::CGO, HWD = C::HWD, NPX = C::NPX, PLX = C::PLX, PLG = C::PLG;
     constexpr int ROWS = C::ROWS, NT = C::NT, CPX = CIN / 8, CPG = COUT / 8;
@@ -86,9 +87,12 @@ __global__ void __launch_bounds__(256) conv_thin_wgrad_k(const ThinWArgs p) {
     const bf16* __restrict__ gy = (const bf16*)p.gy;
 
     const int tiles_per_img = p.tiles_x * p.tiles_y;
-    const int64_t ntiles = (int64_t)tiles_per_img * p.N;
-    const int64_t t0 = ntiles * blockIdx.x / gridDim.x;
-    const int64_t t1 = ntiles * (blockIdx.x + 1) / gridDim.x;
+    const int ntiles = tiles_per_img * p.N;
+    const int t0 = (int)((int64_t)ntiles * blockIdx.x / gridDim.x);
+    const int t1 = (int)((int64_t)ntiles * (blockIdx.x + 1) / gridDim.x);
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.gy), 0, p.g_bytes, 0x00020000);
 
     f32x4 acc[NT][CGO][CGI];
 #pragma unroll
@@ -101,74 +105,87 @@ __global__ void __launch_bounds__(256) conv_thin_wgrad_k(const ThinWArgs p) {
     const int g = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
     const int lane_off = (4 * g + q) * 32 + pp * 8;  // this lane's piece inside a 32-pixel run
 
-    for (int64_t t = t0; t < t1; ++t) {
-        const int n = (int)(t / tiles_per_img);
-        const int rem = (int)(t - (int64_t)n * tiles_per_img);
+    for (int t = t0; t < t1; ++t) {
+        const int n = t / tiles_per_img;
+        const int rem = t - n * tiles_per_img;
         const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
         const int oy0 = ty * TH, ox0 = tx * 32;
         __syncthreads();  // previous tile's fragment reads are done
-        // Staging is branch-free: batches of UB unconditional 16-byte loads (ld16_or_zero), then the LDS
-        // stores; chunk indices past the image go to a per-thread dump slot.
-        constexpr int UB = 8;
+        // Staging is branch-free: batches of UB raw buffer loads (lanes past the image get an out-of-range
+        // offset and read zeros), then the LDS stores; chunk indices past the tile go to a per-thread dump slot.
+        constexpr int UB = 4;
         constexpr int NLX = (C::NCX + 255) / 256, NLG = (C::NCG + 255) / 256;
-        // ---- x halo -> LDS [ci/16][pixel][16] ------------------------------------------------
-#pragma unroll
-        for (int b0 = 0; b0 < NLX; b0 += UB) {
-            uint4 v[UB];
-#pragma unroll
-            for (int k = 0; k < UB; ++k) {
-                if (b0 + k >= NLX) continue;
-                const int idx = (b0 + k) * 256 + tid;
-                const int p8 = idx / (8 * CPX), r8 = idx % (8 * CPX);
-                const int c8 = r8 >> 3;
-                const int pix = p8 * 8 + (r8 & 7);
-                const int hy = pix / HWD, hx = pix - hy * HWD;
-                const int ly = oy0 - p.py + hy, lx = ox0 - p.px + hx;
-                const bool ok = pix < NPX && (unsigned)ly < (unsigned)p.Hl && (unsigned)lx < (unsigned)p.Wl && c8 * 8 < p.Cin;
-                const int64_t off = (((int64_t)n * p.H + (ly >> p.up2)) * p.W + (lx >> p.up2)) * p.Cin + c8 * 8;
-                v[k] = ld16_or_zero(x, off * 2, ok);
+        // ---- x halo -> LDS [ci/16][pixel][16]; 256 % (8*CPX) == 0: a thread's channel chunk is fixed ----
+        {
+            const int c8 = (tid % (8 * CPX)) >> 3;
+            const bool cok = c8 * 8 < p.Cin;
+            float4 s0 = make_float4(1.f, 1.f, 1.f, 1.f), s1 = s0;
+            if (p.in_scale) {
+                const float* sp = p.in_scale + (int64_t)n * p.Cin + (cok ? c8 * 8 : 0);
+                s0 = *reinterpret_cast<const float4*>(sp);
+                s1 = *reinterpret_cast<const float4*>(sp + 4);
             }
 #pragma unroll
-            for (int k = 0; k < UB; ++k) {
-                if (b0 + k >= NLX) continue;
-                const int idx = (b0 + k) * 256 + tid;
-                const int p8 = idx / (8 * CPX), r8 = idx % (8 * CPX);
-                const int c8 = r8 >> 3;
-                const int pix = p8 * 8 + (r8 & 7);
-                uint4 u = v[k];
-                if (p.fu.x_slope != 1.f) u = lrelu_chunk(u, p.fu.x_slope, bf16());
-                if (p.in_scale) u = wmod_chunk(u, p.in_scale + (int64_t)n * p.Cin + (c8 * 8 < p.Cin ? c8 * 8 : 0));
-                char* const dst = pix < NPX ? xl + (c8 >> 1) * PLX + pix * 32 + (c8 & 1) * 16 : dumpl + tid * 16;
-                *reinterpret_cast<uint4*>(dst) = u;
+            for (int b0 = 0; b0 < NLX; b0 += UB) {
+                v4u v[UB];
+#pragma unroll
+                for (int k = 0; k < UB; ++k) {
+                    if (b0 + k >= NLX) continue;
+                    const int idx = (b0 + k) * 256 + tid;
+                    const int pix = (idx / (8 * CPX)) * 8 + (idx & 7);
+                    const int hy = pix / HWD, hx = pix - hy * HWD;
+                    const int ly = oy0 - p.py + hy, lx = ox0 - p.px + hx;
+                    const bool ok = pix < NPX && (unsigned)ly < (unsigned)p.Hl && (unsigned)lx < (unsigned)p.Wl && cok;
+                    const unsigned off = (unsigned)(((n * p.H + (ly >> p.up2)) * p.W + (lx >> p.up2)) * (p.Cin * 2) + c8 * 16);
+                    v[k] = __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? off : 0x80000000u, 0, 0);
+                }
+#pragma unroll
+                for (int k = 0; k < UB; ++k) {
+                    if (b0 + k >= NLX) continue;
+                    const int idx = (b0 + k) * 256 + tid;
+                    const int pix = (idx / (8 * CPX)) * 8 + (idx & 7);
+                    uint4 u = __builtin_bit_cast(uint4, v[k]);
+                    if (p.fu.x_slope != 1.f) u = lrelu_chunk(u, p.fu.x_slope, bf16());
+                    if (p.in_scale) {
+                        bf16x8 h = *reinterpret_cast<bf16x8*>(&u);
+                        h[0] = (bf16)((float)h[0] * s0.x); h[1] = (bf16)((float)h[1] * s0.y);
+                        h[2] = (bf16)((float)h[2] * s0.z); h[3] = (bf16)((float)h[3] * s0.w);
+                        h[4] = (bf16)((float)h[4] * s1.x); h[5] = (bf16)((float)h[5] * s1.y);
+                        h[6] = (bf16)((float)h[6] * s1.z); h[7] = (bf16)((float)h[7] * s1.w);
+                        u = *reinterpret_cast<uint4*>(&h);
+                    }
+                    char* const dst = pix < NPX ? xl + (c8 >> 1) * PLX + pix * 32 + (c8 & 1) * 16 : dumpl + tid * 16;
+                    *reinterpret_cast<uint4*>(dst) = u;
+                }
             }
         }
         // ---- gy tile -> LDS [co/16][pixel][16] (gy_up2: gy is stored at half resolution) --------
-        const int gsh = p.fu.gy_up2;
-        const int Hg = p.Ho >> gsh, Wg = p.Wo >> gsh;
+        {
+            const int c8 = (tid % (8 * CPG)) >> 3;
+            const bool cok = c8 * 8 < p.Cout;
+            const int gsh = p.fu.gy_up2;
+            const int Hg = p.Ho >> gsh, Wg = p.Wo >> gsh;
 #pragma unroll
-        for (int b0 = 0; b0 < NLG; b0 += UB) {
-            uint4 v[UB];
+            for (int b0 = 0; b0 < NLG; b0 += UB) {
+                v4u v[UB];
 #pragma unroll
-            for (int k = 0; k < UB; ++k) {
-                if (b0 + k >= NLG) continue;
-                const int idx = (b0 + k) * 256 + tid;
-                const int p8 = idx / (8 * CPG), r8 = idx % (8 * CPG);
-                const int c8 = r8 >> 3;
-                const int pix = p8 * 8 + (r8 & 7);
-                const int oy = oy0 + (pix >> 5), ox = ox0 + (pix & 31);
-                const bool ok = idx < C::NCG && oy < p.Ho && ox < p.Wo && c8 * 8 < p.Cout;
-                const int64_t off = (((int64_t)n * Hg + (oy >> gsh)) * Wg + (ox >> gsh)) * p.Cout + c8 * 8;
-                v[k] = ld16_or_zero(gy, off * 2, ok);
-            }
+                for (int k = 0; k < UB; ++k) {
+                    if (b0 + k >= NLG) continue;
+                    const int idx = (b0 + k) * 256 + tid;
+                    const int pix = (idx / (8 * CPG)) * 8 + (idx & 7);
+                    const int oy = oy0 + (pix >> 5), ox = ox0 + (pix & 31);
+                    const bool ok = idx < C::NCG && oy < p.Ho && ox < p.Wo && cok;
+                    const unsigned off = (unsigned)(((n * Hg + (oy >> gsh)) * Wg + (ox >> gsh)) * (p.Cout * 2) + c8 * 16);
+                    v[k] = __builtin_amdgcn_raw_buffer_load_b128(rg, ok ? off : 0x80000000u, 0, 0);
+                }
 #pragma unroll
-            for (int k = 0; k < UB; ++k) {
-                if (b0 + k >= NLG) continue;
-                const int idx = (b0 + k) * 256 + tid;
-                const int p8 = idx / (8 * CPG), r8 = idx % (8 * CPG);
-                const int c8 = r8 >> 3;
-                const int pix = p8 * 8 + (r8 & 7);
-                char* const dst = idx < C::NCG ? gl + (c8 >> 1) * PLG + pix * 32 + (c8 & 1) * 16 : dumpl + tid * 16;
-                *reinterpret_cast<uint4*>(dst) = v[k];
+                for (int k = 0; k < UB; ++k) {
+                    if (b0 + k >= NLG) continue;
+                    const int idx = (b0 + k) * 256 + tid;
+                    const int pix = (idx / (8 * CPG)) * 8 + (idx & 7);
+                    char* const dst = idx < C::NCG ? gl + (c8 >> 1) * PLG + pix * 32 + (c8 & 1) * 16 : dumpl + tid * 16;
+                    *reinterpret_cast<uint4*>(dst) = __builtin_bit_cast(uint4, v[k]);
+                }
             }
         }
         __syncthreads();
@@ -282,7 +299,10 @@ int gan_conv2d_wgrad_thin(const void* x, const void* gy, float* dw, const float*
     if (kh != kw || (kh != 1 && kh != 3)) return 0;
     if (py != (kh - 1) / 2 || px != py) return 0;
     if (Cin > 64 || Cout > 64 || (Cin & 7) || (Cout & 7) || Wo < 32 || Ho < 8) return 0;
+    const int64_t xb = (int64_t)N * H * W * Cin * 2, gb = (int64_t)N * (Ho >> fu.gy_up2) * (Wo >> fu.gy_up2) * Cout * 2;
+    if (xb >= (1LL << 31) || gb >= (1LL << 31) || ((uintptr_t)in_scale & 15)) return 0;
     ThinWArgs a;
+    a.x_bytes = (unsigned)xb; a.g_bytes = (unsigned)gb;
     a.fu = fu;
     a.x = x; a.gy = gy; a.dw = dw; a.in_scale = in_scale;
     a.N = N; a.H = H; a.W = W; a.Hl = up2 ? 2 * H : H; a.Wl = up2 ? 2 * W : W; a.up2 = up2;
