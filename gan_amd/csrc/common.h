@@ -98,6 +98,14 @@ __device__ __forceinline__ uint4 ld16_or_zero(const void* base, int64_t elem_off
     return ok ? v : make_uint4(0u, 0u, 0u, 0u);
 }
 
+// value of lane ^ 1 / lane ^ 2 within each quad, as a DPP move (no trip through the LDS crossbar like __shfl_xor)
+__device__ __forceinline__ float quad_xor1(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float quad_xor2(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+}
+
 __device__ __forceinline__ float lrelu_f(float v, float slope) { return v > 0.f ? v : v * slope; }
 __device__ __forceinline__ float lrelu_mask(float y, float slope) { return y > 0.f ? 1.f : slope; }
 
@@ -130,6 +138,12 @@ int gan_conv2d_fwd_thin(const void* x, const void* wt, void* y, const float* in_
                         const float* bias, const void* noise, const float* noise_scale, float slope, int N, int H,
                         int W, int Cin, int up2, int Ho, int Wo, int Cout, int kh, int kw, int py, int px, int Kpad,
                         const ConvFuse& fu, hipStream_t st);
+
+// conv_wide.hip: LDS-DMA implicit GEMM for Cin % 64 == 0 (bf16, no input-side stages).  1 / 0 / < 0 as above.
+int gan_conv2d_fwd_wide(const void* x, const void* wt, void* y, const float* out_scale, const float* bias,
+                        const void* noise, const float* noise_scale, float slope, int N, int H, int W, int Cin, int up2,
+                        int Ho, int Wo, int Cout, int kh, int kw, int py, int px, int Kpad, const ConvFuse& fu,
+                        hipStream_t st);
 
 // Fused stages of the weight gradient (include/gan_amd.h): leaky-ReLU of x as it is staged, gy given at half
 // resolution (nearest-neighbour upsampled in the gather: the adjoint of 2x2 pooling, with gain 0.25), scalar gain.

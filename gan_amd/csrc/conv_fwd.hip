@@ -385,5 +385,10 @@ extern "C" int gan_conv2d_fwd(const void* x, const void* wt, void* y, const floa
     const int thin = gan_conv2d_fwd_thin(x, wt, y, in_scale, out_scale, bias, noise, noise_scale, slope, N, H, W, Cin,
                                          up2, Ho, Wo, Cout, kh, kw, py, px, Kpad, a.fu, st);
     if (thin != 0) return thin < 0 ? thin : GAN_OK;
+    if (!in_scale) {
+        const int wide = gan_conv2d_fwd_wide(x, wt, y, out_scale, bias, noise, noise_scale, slope, N, H, W, Cin, up2, Ho, Wo,
+                                             Cout, kh, kw, py, px, Kpad, a.fu, st);
+        if (wide != 0) return wide < 0 ? wide : GAN_OK;
+    }
     return launch<bf16>(a, st);
 }

@@ -287,7 +287,7 @@ __global__ void __launch_bounds__(256, 2) conv_thin_k(const ThinArgs p) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             const float a = acc[i][fa][j] + acc[i][fa + 2][j];
-                            v[j] = (a + __shfl_xor(a, 1)) * gain;
+                            v[j] = (a + quad_xor1(a)) * gain;
                         }
                     } else {
 #pragma unroll

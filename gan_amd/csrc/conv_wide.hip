@@ -1,0 +1,258 @@
+// Implicit-GEMM convolution for WIDE layers on MFMA (gfx950), bf16: Cin % 64 == 0 (128..512 channels on
+// 4x4..64x64 maps: the inner blocks of the StyleGAN2 generator and discriminator, modelling/stylegan2.py:29-36,
+// modelling/progressive_gan.py:45-50,61, and their input gradients).
+//
+//   D[co][m] = sum_k Wt[co][k] * X[pix(m) + tap(k)][ci(k)],   k = tap*Cin + ci,   M = N*Ho*Wo pixels
+//
+// Same GEMM as conv_fwd.hip; what differs is how the operand tiles reach LDS and how deep a step is:
+//   * BK = 64: a K step is 64 consecutive channels of ONE tap (Cin % 64 == 0), i.e. one 128-byte run per
+//     pixel row and per weight row;
+//   * both tiles are written to LDS by LDS-DMA (`buffer_load_dwordx4 ... lds`, 16 bytes per lane, 1 KiB per
+//     wave instruction): no staging registers, no ds_write pass, no VALU beyond the address; lanes whose tap
+//     falls outside the image (zero padding) or past M / Cout get an out-of-range buffer offset and the
+//     hardware writes zeros.  Nearest-2x upsampling is part of the address;
+//   * the LDS image of a wave instruction is lane-linear (8 rows x 128 B), so the bank swizzle is applied on
+//     the SOURCE side: slot `pos` of row r holds chunk pos ^ (r & 7); fragment reads use the same XOR;
+//   * two LDS stages; the DMA of step s+1 is in flight while step s is on the matrix cores;
+//   * operand roles are swapped (A = weights, B = pixels) so a lane owns 4 consecutive output channels of one
+//     pixel: 8-byte stores, and with the pooled row order (2x2 window = 4 consecutive rows = 4 adjacent
+//     lanes) AvgPool2d is two cross-lane adds.
+// Input-side stages (style modulation, leaky-ReLU before the convolution) cannot ride on LDS-DMA; callers
+// apply them in a pass of their own for these layers (the tensors are small: <= 134 MB at batch 256), or the
+// register-staged kernel in conv_fwd.hip takes the call.
+#include "common.h"
+
+namespace {
+
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+constexpr unsigned WIDE_INV = 0x80000000u;
+
+struct WideArgs {
+    const void* x;
+    const void* wt;
+    void* y;
+    const float* out_scale;
+    const float* bias;
+    const void* noise;
+    const float* noise_scale;
+    const void* aux;
+    float slope, aux_slope, gain;
+    int N, H, W, Cin, Hl, Wl, up2, Ho, Wo, Cout, kw, py, px, Kpad, ksteps, pool;
+    int M;
+    unsigned x_bytes, w_bytes, y_bytes;
+};
+
+template <int BN>
+__global__ void __launch_bounds__(256, 2) conv_wide_k(const WideArgs p) {
+    constexpr int BM = 128, FP = 4, FC = BN / 32;          // wave tile: 64 pixels x BN/2 channels
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;  // one stage: pixel tile, weight tile (64 k each)
+    constexpr int STAGE = A_BYTES + B_BYTES;
+    __shared__ __attribute__((aligned(1024))) char lds[2 * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int bm0 = blockIdx.x * BM, bn0 = blockIdx.y * BN;
+    const int HoWo = p.Ho * p.Wo;
+
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wt), 0, p.w_bytes, 0x00020000);
+
+    // ---- staging bookkeeping: wave instruction j covers rows (4j + wave)*8 .. +7, 8 lanes per row ----------
+    const int rsub = lane >> 3;
+    const int csrc = (lane & 7) ^ rsub;  // source chunk of this lane's LDS slot
+    int a_n[4], a_yx[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m = bm0 + (4 * j + wave) * 8 + rsub;
+        const bool ok = m < p.M;
+        const int mm = ok ? m : 0;
+        const int n = mm / HoWo;
+        const int rem = mm - n * HoWo;
+        int oy, ox;
+        if (p.pool) {  // quad-major rows: 4q..4q+3 are the 2x2 window of pooled pixel q
+            const int q = rem >> 2, wo2 = p.Wo >> 1;
+            const int qy = q / wo2;
+            oy = 2 * qy + ((rem >> 1) & 1);
+            ox = 2 * (q - qy * wo2) + (rem & 1);
+        } else {
+            oy = rem / p.Wo;
+            ox = rem - oy * p.Wo;
+        }
+        a_n[j] = ok ? n : -1;
+        a_yx[j] = (oy << 16) | ox;
+    }
+    unsigned b_off[BN / 32];
+#pragma unroll
+    for (int j = 0; j < BN / 32; ++j) {
+        const int co = bn0 + (4 * j + wave) * 8 + rsub;
+        b_off[j] = co < p.Cout ? (unsigned)(co * p.Kpad + csrc * 8) * 2u : WIDE_INV;
+    }
+
+    auto issue = [&](int s, int buf) {
+        const int k0 = s * 64;
+        const int tap = k0 / p.Cin;
+        const int cb = k0 - tap * p.Cin;
+        const int dy = tap / p.kw;
+        const int dx = tap - dy * p.kw;
+        char* const A = lds + buf * STAGE;
+        char* const B = A + A_BYTES;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int iy = (a_yx[j] >> 16) + dy - p.py;
+            const int ix = (a_yx[j] & 0xffff) + dx - p.px;
+            const bool ok = a_n[j] >= 0 && (unsigned)iy < (unsigned)p.Hl && (unsigned)ix < (unsigned)p.Wl;
+            const unsigned off = (unsigned)(((a_n[j] * p.H + (iy >> p.up2)) * p.W + (ix >> p.up2)) * p.Cin + cb + csrc * 8) * 2u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(A + (4 * j + wave) * 1024), 16,
+                                                     ok ? off : WIDE_INV, 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < BN / 32; ++j) {
+            const unsigned off = b_off[j] == WIDE_INV ? WIDE_INV : b_off[j] + (unsigned)k0 * 2u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(B + (4 * j + wave) * 1024), 16, off, 0,
+                                                     0, 0);
+        }
+    };
+
+    f32x4 acc[FC][FP];
+#pragma unroll
+    for (int i = 0; i < FC; ++i)
+#pragma unroll
+        for (int f = 0; f < FP; ++f) acc[i][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int frow = lane & 15, fq = lane >> 4;
+    // byte offset of this lane's fragment chunk (k half h) inside a 128-byte row r: ((4h + fq) ^ (r & 7)) * 16;
+    // r & 7 == frow & 7 for every fragment row (tile offsets are multiples of 16)
+    const int sw0 = ((fq) ^ (frow & 7)) << 4, sw1 = ((4 + fq) ^ (frow & 7)) << 4;
+    const int xrow = (wm * 64 + frow) * 128, wrow = (wn * (BN / 2) + frow) * 128;
+
+    issue(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (int s = 0; s < p.ksteps; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < p.ksteps) issue(s + 1, buf ^ 1);
+        const char* const A = lds + buf * STAGE;
+        const char* const B = A + A_BYTES;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int sw = h ? sw1 : sw0;
+            bf16x8 wf[FC], xf[FP];
+#pragma unroll
+            for (int i = 0; i < FC; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(B + wrow + i * 16 * 128 + sw);
+#pragma unroll
+            for (int f = 0; f < FP; ++f) xf[f] = *reinterpret_cast<const bf16x8*>(A + xrow + f * 16 * 128 + sw);
+#pragma unroll
+            for (int i = 0; i < FC; ++i)
+#pragma unroll
+                for (int f = 0; f < FP; ++f) acc[i][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[f], acc[i][f], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next stage has landed (this wave's share)
+        __syncthreads();                                  // ... everyone's, and everyone is done reading this one
+    }
+
+    // ---- epilogue: lane holds channels co0..co0+3 (co0 = bn0 + wn*BN/2 + 16*i + 4*fq) of pixel row f*16 + frow
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t raux = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.aux), 0, p.aux ? p.y_bytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rnz =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.noise), 0, p.noise ? p.y_bytes / (unsigned)p.Cout : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rosc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.out_scale), 0, p.out_scale ? (unsigned)(p.N * p.Cout) * 4u : 0u, 0x00020000);
+    const int out_per_img = p.pool ? HoWo >> 2 : HoWo;
+    const float gain = p.pool ? 0.25f * p.gain : p.gain;
+    float4 bia[FC], nsc[FC];
+    int co0[FC];
+#pragma unroll
+    for (int i = 0; i < FC; ++i) {
+        co0[i] = bn0 + wn * (BN / 2) + i * 16 + fq * 4;
+        const bool cok = co0[i] < p.Cout;  // Cout % 4 == 0
+        bia[i] = (p.bias && cok) ? *reinterpret_cast<const float4*>(p.bias + co0[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        nsc[i] = (p.noise_scale && cok) ? *reinterpret_cast<const float4*>(p.noise_scale + co0[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int f = 0; f < FP; ++f) {
+        const int m = bm0 + wm * 64 + f * 16 + frow;
+        const bool live = m < p.M && (!p.pool || (frow & 3) == 0);
+        const int opix = p.pool ? m >> 2 : m;
+        const int n = opix / out_per_img;
+        const unsigned obase = live ? (unsigned)opix * (unsigned)(p.Cout * 2) : WIDE_INV;
+        // every per-pixel load of this fragment row first, then its stores
+        float nz = 0.f;
+        if (p.noise) nz = (float)__builtin_bit_cast(bf16, __builtin_amdgcn_raw_buffer_load_b16(rnz, live ? (unsigned)opix * 2u : WIDE_INV, 0, 0));
+        v2u ax[FC];
+        v4u os[FC];
+#pragma unroll
+        for (int i = 0; i < FC; ++i) {
+            const bool cok = live && co0[i] < p.Cout;
+            ax[i] = __builtin_amdgcn_raw_buffer_load_b64(raux, cok ? obase + co0[i] * 2 : WIDE_INV, 0, 0);
+            os[i] = __builtin_amdgcn_raw_buffer_load_b128(rosc, cok ? (unsigned)(n * p.Cout + co0[i]) * 4u : WIDE_INV, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < FC; ++i) {
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float a = acc[i][f][r];
+                if (p.pool) {  // executed by every lane: the window's four pixels are four adjacent lanes
+                    a += quad_xor1(a);
+                    a += quad_xor2(a);
+                }
+                v[r] = a * gain;
+            }
+            const float4 d4 = p.out_scale ? __builtin_bit_cast(float4, os[i]) : make_float4(1.f, 1.f, 1.f, 1.f);
+            v[0] = fmaf(nz, nsc[i].x, fmaf(v[0], d4.x, bia[i].x));
+            v[1] = fmaf(nz, nsc[i].y, fmaf(v[1], d4.y, bia[i].y));
+            v[2] = fmaf(nz, nsc[i].z, fmaf(v[2], d4.z, bia[i].z));
+            v[3] = fmaf(nz, nsc[i].w, fmaf(v[3], d4.w, bia[i].w));
+            bf16x4 o;
+            const bf16x4 a4 = __builtin_bit_cast(bf16x4, ax[i]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float u = lrelu_f(v[r], p.slope);
+                if (p.aux) u *= lrelu_mask((float)a4[r], p.aux_slope);
+                o[r] = (bf16)u;
+            }
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, o), ry, (live && co0[i] < p.Cout) ? obase + co0[i] * 2 : WIDE_INV, 0, 0);
+        }
+    }
+}
+
+}  // namespace
+
+// 1 = served, 0 = shape not eligible, < 0 = error.  Never takes in_scale / in_slope (see the header comment).
+int gan_conv2d_fwd_wide(const void* x, const void* wt, void* y, const float* out_scale, const float* bias,
+                        const void* noise, const float* noise_scale, float slope, int N, int H, int W, int Cin, int up2,
+                        int Ho, int Wo, int Cout, int kh, int kw, int py, int px, int Kpad, const ConvFuse& fu,
+                        hipStream_t st) {
+    if (Cin % 64 != 0 || Kpad != kh * kw * Cin || (Cout & 3) || fu.in_slope != 1.f) return 0;
+    const int64_t M = (int64_t)N * Ho * Wo;
+    const int64_t xb = (int64_t)N * H * W * Cin * 2, wb = (int64_t)Cout * Kpad * 2;
+    const int64_t yb = (fu.pool ? M / 4 : M) * Cout * 2;
+    if (M < 128 || M >= (1LL << 31) - 256 || xb >= (1LL << 31) || wb >= (1LL << 31) || yb >= (1LL << 31)) return 0;
+    if (((uintptr_t)y & 7) || ((uintptr_t)fu.aux & 7) || ((uintptr_t)out_scale & 15) || ((uintptr_t)bias & 15) ||
+        ((uintptr_t)noise_scale & 15))
+        return 0;
+    if (H >= 32768 || W >= 32768) return 0;
+    WideArgs a;
+    a.x = x; a.wt = wt; a.y = y; a.out_scale = out_scale; a.bias = bias; a.noise = noise; a.noise_scale = noise_scale;
+    a.aux = fu.aux; a.slope = slope; a.aux_slope = fu.aux_slope; a.gain = fu.gain;
+    a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Hl = up2 ? 2 * H : H; a.Wl = up2 ? 2 * W : W; a.up2 = up2;
+    a.Ho = Ho; a.Wo = Wo; a.Cout = Cout; a.kw = kw; a.py = py; a.px = px; a.Kpad = Kpad; a.ksteps = Kpad / 64;
+    a.pool = fu.pool; a.M = (int)M;
+    a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb; a.y_bytes = (unsigned)yb;
+    const unsigned gm = (unsigned)((M + 127) / 128);
+    if (Cout > 64) {
+        const unsigned gn = (unsigned)((Cout + 127) / 128);
+        if (gn > 65535) return 0;
+        hipLaunchKernelGGL(conv_wide_k<128>, dim3(gm, gn), dim3(256), 0, st, a);
+    } else {
+        hipLaunchKernelGGL(conv_wide_k<64>, dim3(gm, 1), dim3(256), 0, st, a);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        gan_set_error("conv2d_fwd(wide): launch failed: %s", hipGetErrorString(e));
+        return GAN_ERR_LAUNCH;
+    }
+    return 1;
+}

@@ -285,6 +285,15 @@ def pack_weight(weight: Tensor, dtype: torch.dtype, cin_mult: int = 8, transpose
 PACK_STATS = [0, 0]  # hits, misses (cacheable tensors only)
 
 
+def _wide_kernel_shape(x: Tensor, cin_p: int, cout: int, ho: int, wo: int, kh: int, kw: int, py: int, px: int) -> bool:
+    """Mirror of the C-side dispatch (conv_fwd.hip: thin kernel first, then conv_wide.hip's eligibility)."""
+    if x.dtype != torch.bfloat16 or cin_p % 64 != 0 or cout % 4 != 0 or x.shape[0] * ho * wo < 128:
+        return False
+    thin = (kh == kw and kh in (1, 3) and py == px == (kh - 1) // 2 and cin_p in (8, 16, 32, 64) and cout <= 64
+            and wo >= 32 and ho >= 8)
+    return not thin
+
+
 def raw_conv2d(
     x: Tensor,
     weight: Tensor,
@@ -327,6 +336,15 @@ def raw_conv2d(
         in_scale = _f32(in_scale).reshape(n, cin)
         if cin_p != cin:
             in_scale = F.pad(in_scale, (0, cin_p - cin)).contiguous()
+    if (in_scale is not None or in_slope != 1.0) and _wide_kernel_shape(x, cin_p, cout, ho, wo, kh, kw, py, px):
+        # The LDS-DMA kernel of the wide layers (conv_wide.hip) has no input-side stages: its operand tiles
+        # never pass through registers.  Activation / modulation run as one pass over these small tensors.
+        if in_slope != 1.0:
+            x = raw_affine_act(x, slope=in_slope)
+            in_slope = 1.0
+        if in_scale is not None:
+            x = raw_affine_act(x, a=in_scale)
+            in_scale = None
     out_scale32, _ = _side(out_scale, n, cout, "conv2d out_scale")
     if out_scale32 is not None and out_scale32.numel() != n * cout:
         out_scale32 = out_scale32.reshape(1, cout).expand(n, cout).contiguous()

@@ -485,3 +485,63 @@ def test_conv2d_act_pool_second_order(dev):
     hx, hw = torch.autograd.grad(gx.square().sum() + gw.square().sum(), [xg, wg])
     assert rel_err(gx, gx_ref) < TOL32 and rel_err(gw, gw_ref) < TOL32
     assert rel_err(hx, hx_ref) < TOL32_2 and rel_err(hw, hw_ref) < TOL32_2
+
+
+WIDE_CASES = [
+    # N, Cin, H, W, Cout, k, up2, pool   (bf16, Cin % 64 == 0, not thin: conv_wide.hip, LDS-DMA staging)
+    (4, 128, 32, 32, 128, 3, False, False),
+    (3, 128, 32, 32, 256, 3, False, True),
+    (8, 512, 8, 8, 512, 3, False, False),
+    (5, 512, 4, 4, 512, 3, False, False),  # M = 80 < 128: the register-staged kernel takes it
+    (9, 256, 4, 4, 512, 3, False, True),
+    (4, 256, 8, 8, 128, 3, True, False),  # nearest-2x in the address
+    (2, 128, 32, 32, 64, 3, True, False),  # Cout = 64: BN = 64 tile
+    (3, 64, 64, 64, 128, 3, False, True),
+    (4, 256, 16, 16, 512, 1, False, True),  # D shortcut: 1x1 conv -> pool
+    (3, 192, 13, 9, 72, 3, False, False),  # ragged M, Cout tail
+    (2, 128, 19, 7, 20, 1, False, False),
+]
+
+
+@pytest.mark.parametrize("case", WIDE_CASES)
+def test_conv2d_wide_kernel(dev, case):
+    """LDS-DMA implicit GEMM with every output-side stage, and the input-side ones through their own pass."""
+    import gan_amd.functional as GF
+    from oracle import gan_oracle as O
+
+    n, cin, h, w, cout, k, up2, pool = case
+    torch.manual_seed(31)
+    pad = (k - 1) // 2
+    x = torch.randn(n, cin, h, w).bfloat16()
+    wgt = (torch.randn(cout, cin, k, k) / (cin * k * k) ** 0.5).bfloat16().float()
+    s = torch.randn(n, cin) * 0.5 + 1
+    d = torch.rand(n, cout) + 0.5
+    b = torch.randn(cout)
+    ns = torch.randn(cout)
+    ho, wo = (2 * h, 2 * w) if up2 else (h, w)
+    hy, wy = (ho // 2, wo // 2) if pool else (ho, wo)
+    noise = torch.randn(n, 1, hy, wy).bfloat16()
+    aux = torch.randn(n, cout, hy, wy).bfloat16()
+    xl = O.nearest_up2(x.double()) if up2 else x.double()
+    # generator-style call: modulation, demodulation, bias, noise, activation
+    xs = (xl * s.double().view(n, cin, 1, 1)).bfloat16().double()
+    z = F.conv2d(xs, wgt.double(), padding=pad)
+    if pool:
+        z = F.avg_pool2d(z, 2)
+    ref = z * d.double().view(n, cout, 1, 1) + b.double().view(1, -1, 1, 1)
+    ref = F.leaky_relu(ref + noise.double() * ns.double().view(1, -1, 1, 1), 0.2)
+    got = GF.raw_conv2d(
+        x.to(dev), wgt.to(dev), pad, pad, up2=up2, in_scale=s.to(dev), out_scale=d.to(dev), bias=b.to(dev),
+        noise=noise.to(dev), noise_scale=ns.to(dev), slope=0.2, pool=pool,
+    )
+    assert got.shape == ref.shape and got.dtype == torch.bfloat16
+    assert rel_err(got, ref) < 4e-3, rel_err(got, ref)
+    # discriminator-style call: activation before, gain, mask after
+    xa = F.leaky_relu(xl, 0.2).bfloat16().double()
+    z = F.conv2d(xa, wgt.double(), padding=pad) * 0.25
+    if pool:
+        z = F.avg_pool2d(z, 2)
+    ref2 = (z + b.double().view(1, -1, 1, 1)) * torch.where(aux.double() > 0, 1.0, 0.2)
+    got2 = GF.raw_conv2d(x.to(dev), wgt.to(dev), pad, pad, up2=up2, bias=b.to(dev), in_slope=0.2, pool=pool,
+                         aux=aux.to(dev), aux_slope=0.2, gain=0.25)
+    assert rel_err(got2, ref2) < 4e-3, rel_err(got2, ref2)
