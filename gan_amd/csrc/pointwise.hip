@@ -543,3 +543,46 @@ extern "C" int gan_ema_lerp(float* ema, const float* p, int64_t n, float weight,
     GAN_CHECK_LAUNCH("ema_lerp");
     return GAN_OK;
 }
+
+
+// ---- weight packing -------------------------------------------------------------------------
+// (Cout, Cin, kh, kw) parameter -> GEMM-B image [rows][Kpad], k = tap*Cin_p + ci, zero padded, in the compute
+// dtype; `transposed` packs the flipped, channel-swapped weights of the input-gradient correlation
+// (rows = Cin, ci <- co, tap <- kh*kw-1-tap).  One launch instead of flip + permute + pad + cast.
+template <typename TI, typename TO>
+__global__ void __launch_bounds__(256) pack_weight_k(const TI* __restrict__ w, TO* __restrict__ out, int Cout, int Cin, int taps,
+                                                     int rows, int cols, int cols_p, int Kpad, int transposed) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (int64_t)rows * Kpad) return;
+    const int r = (int)(e / Kpad), k = (int)(e - (int64_t)r * Kpad);
+    const int tap = k / cols_p, c = k - tap * cols_p;
+    float v = 0.f;
+    if (tap < taps && c < cols) {
+        const int co = transposed ? c : r, ci = transposed ? r : c;
+        const int t = transposed ? taps - 1 - tap : tap;
+        v = (float)w[((int64_t)co * Cin + ci) * taps + t];
+    }
+    out[e] = (TO)v;
+}
+
+extern "C" int gan_pack_weight(const void* w, int w_dtype, void* out, int out_dtype, int Cout, int Cin, int kh, int kw,
+                               int cols_p, int Kpad, int transposed, gan_stream_t stream) {
+    GAN_CHECK_ARG(w && out, "pack_weight: null pointer");
+    GAN_CHECK_ARG((w_dtype == GAN_F32 || w_dtype == GAN_BF16) && (out_dtype == GAN_F32 || out_dtype == GAN_BF16), "pack_weight: bad dtype");
+    GAN_CHECK_ARG(Cout > 0 && Cin > 0 && kh > 0 && kw > 0, "pack_weight: bad shape");
+    const int rows = transposed ? Cin : Cout, cols = transposed ? Cout : Cin, taps = kh * kw;
+    GAN_CHECK_ARG(cols_p >= cols && Kpad >= taps * cols_p, "pack_weight: padded sizes too small");
+    const int64_t total = (int64_t)rows * Kpad;
+    const int64_t blocks = ceil_div64(total, 256);
+    GAN_CHECK_ARG(blocks < (1LL << 31), "pack_weight: too large");
+    hipStream_t st = (hipStream_t)stream;
+#define PACK_LAUNCH(TI, TO) \
+    hipLaunchKernelGGL((pack_weight_k<TI, TO>), dim3((unsigned)blocks), dim3(256), 0, st, (const TI*)w, (TO*)out, Cout, Cin, taps, rows, cols, cols_p, Kpad, transposed)
+    if (w_dtype == GAN_F32 && out_dtype == GAN_BF16) PACK_LAUNCH(float, bf16);
+    else if (w_dtype == GAN_F32) PACK_LAUNCH(float, float);
+    else if (out_dtype == GAN_BF16) PACK_LAUNCH(bf16, bf16);
+    else PACK_LAUNCH(bf16, float);
+#undef PACK_LAUNCH
+    GAN_CHECK_LAUNCH("pack_weight");
+    return GAN_OK;
+}

@@ -243,19 +243,21 @@ def _pad_channels(x: Tensor, mult: int) -> Tensor:
 
 
 def _pack_weight(weight: Tensor, dtype: torch.dtype, cin_mult: int, transposed: bool) -> Tuple[Tensor, int, int]:
-    if transposed:  # the correlation whose result is the input gradient: swap channels, flip the taps
-        weight = weight.flip(2, 3).transpose(0, 1)
     cout, cin, kh, kw = weight.shape
-    w = weight.permute(0, 2, 3, 1)  # (Cout, kh, kw, Cin)
-    cin_p = cin + ((-cin) % cin_mult)
-    if cin_p != cin:
-        w = F.pad(w, (0, cin_p - cin))
-    k = kh * kw * cin_p
+    rows, cols = (cin, cout) if transposed else (cout, cin)
+    cols_p = cols + ((-cols) % cin_mult)
+    k = kh * kw * cols_p
     kpad = k + ((-k) % 32)
-    w = w.reshape(cout, k)
-    if kpad != k:
-        w = F.pad(w, (0, kpad - k))
-    return w.to(dtype).contiguous(), cin_p, kpad
+    if weight.dtype not in (torch.float32, torch.bfloat16):
+        weight = weight.float()
+    weight = weight.contiguous()
+    out = torch.empty((rows, kpad), dtype=dtype, device=weight.device)
+    check(
+        _lib.load().gan_pack_weight(ptr(weight), dtype_code(weight), ptr(out), dtype_code(out), cout, cin, kh, kw, cols_p, kpad,
+                                    int(transposed), stream_of(weight)),
+        "gan_pack_weight",
+    )
+    return out, cols_p, kpad
 
 
 # Packed GEMM-B images of the PARAMETERS, reused until the optimizer's in-place update bumps the tensor

@@ -125,6 +125,13 @@ int gan_conv2d_wgrad(const void* x, const void* gy, float* dw, const float* in_s
                      int up2, int Ho, int Wo, int Cout, int kh, int kw, int py, int px, float* workspace,
                      int64_t workspace_floats, float x_slope, int gy_up2, float gain, int dtype, gan_stream_t stream);
 
+/* Packs a (Cout, Cin, kh, kw) weight tensor (w_dtype) into the GEMM-B image the convolutions above take:
+ * out[row][Kpad] in out_dtype, k = tap*cols_p + c, zero padded.  transposed = 0: rows = Cout, c = ci;
+ * transposed = 1: the flipped, channel-swapped weights of the input-gradient correlation (rows = Cin, c = co,
+ * tap reversed).  Host-side glue of the reference (the weight is used as is by F.conv2d, stylegan2.py:36). */
+int gan_pack_weight(const void* w, int w_dtype, void* out, int out_dtype, int Cout, int Cin, int kh, int kw, int cols_p,
+                    int Kpad, int transposed, gan_stream_t stream);
+
 /* ---- MinibatchStdDev ---------------------------------------------------------------------
  * replaces MinibatchStdDev.forward   modelling/progressive_gan.py:20-36
  * stat[j] = mean_{c,h,w} sqrt( var_k x[j + k*M] + 1e-6 ),  M = N/G, population variance over the

