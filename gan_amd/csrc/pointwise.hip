@@ -464,6 +464,229 @@ extern "C" int gan_chan_dot(const void* A, const void* B, int b_mode, const void
 }
 
 // =========================================================================================
+// Fused passes of the modulated convolution's backward (autograd of ModulatedConv2d, stylegan2.py:29-36):
+// what used to be three channel reductions and a mask/scale pass over the same two tensors is ONE pass.
+//   modconv_bwd_pre:  gz = gy * m(y) * dinv[n,c];  sums[n][0][c] = sum_hw gy*m(y)        (bias gradient)
+//                                                  sums[n][1][c] = sum_hw gy*m(y)*noise  (noise-scale gradient)
+//                                                  sums[n][2][c] = sum_hw gy*y           (demodulation gradient)
+//   scale_dot:        out = A * a[n,c];            dot[n][c]     = sum_hw A*B            (style gradient + dx)
+// Thread mapping and the block reduction are chan_dot_k's.
+// =========================================================================================
+template <int V>
+__device__ __forceinline__ void chan_block_reduce(float (&acc)[V], float* red, float* __restrict__ dst, int CVT, int R, int cv,
+                                                  int tv, int tr, int vec, int c) {
+    const int tid = threadIdx.x;
+    const bool pow2 = (CVT & (CVT - 1)) == 0 && CVT < 64;
+    __syncthreads();  // `red` may still be read by the previous reduction
+    if (pow2) {
+        for (int off = CVT; off < 64; off <<= 1) {
+#pragma unroll
+            for (int e = 0; e < V; ++e) acc[e] += __shfl_xor(acc[e], off);
+        }
+        const int lane = tid & 63, wave = tid >> 6;
+        if (lane < CVT) {
+#pragma unroll
+            for (int e = 0; e < V; ++e) red[(wave * CVT + lane) * V + e] = acc[e];
+        }
+        __syncthreads();
+        if (tid < CVT && (blockIdx.z * CVT + tid) < cv) {
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                float sum = 0.f;
+                for (int w = 0; w < TPB / 64; ++w) sum += red[(w * CVT + tid) * V + e];
+                atomicAdd(dst + (int64_t)(blockIdx.z * CVT + tid) * V + e, sum);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < V; ++e) red[tid * V + e] = acc[e];
+        __syncthreads();
+        if (tr == 0 && vec < cv) {
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                float sum = 0.f;
+                for (int r = 0; r < R; ++r) sum += red[(r * CVT + tv) * V + e];
+                atomicAdd(dst + c + e, sum);
+            }
+        }
+    }
+}
+
+template <typename T, int V>
+__global__ void __launch_bounds__(TPB) modconv_bwd_pre_k(const T* __restrict__ gy, const T* __restrict__ y, const T* __restrict__ noise,
+                                                         const float* __restrict__ dinv, float slope, T* __restrict__ gz,
+                                                         float* __restrict__ sums, int64_t HW, int C, int CVT, int R,
+                                                         int64_t rows_per_block) {
+    __shared__ float red[TPB * V];
+    const int tid = threadIdx.x;
+    const int tv = tid % CVT, tr = tid / CVT;
+    const int64_t n = blockIdx.y;
+    const int cv = C / V;
+    const int vec = blockIdx.z * CVT + tv;
+    const bool active = (tr < R) && (vec < cv);
+    const int c = vec * V;
+    float a0[V], a1[V], a2[V], dv[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+        a0[e] = a1[e] = a2[e] = 0.f;
+        dv[e] = (dinv && active) ? dinv[n * C + c + e] : 1.f;
+    }
+    if (active) {
+        const int64_t row0 = (int64_t)blockIdx.x * rows_per_block;
+        int64_t row1 = row0 + rows_per_block;
+        if (row1 > HW) row1 = HW;
+        for (int64_t row = row0 + tr; row < row1; row += R) {
+            const int64_t pix = n * HW + row;
+            const int64_t off = pix * C + c;
+            float g[V], yv[V], o[V];
+            load_f<T, V>(gy + off, g);
+            if (y) load_f<T, V>(y + off, yv);
+            const float nz = noise ? (float)noise[pix] : 0.f;
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                const float gm = y ? g[e] * lrelu_mask(yv[e], slope) : g[e];
+                a0[e] += gm;
+                a1[e] = fmaf(gm, nz, a1[e]);
+                if (y) a2[e] = fmaf(g[e], yv[e], a2[e]);
+                o[e] = gm * dv[e];
+            }
+            store_f<T, V>(gz + off, o);
+        }
+    }
+    float* const dst = sums + n * 3 * C;
+    chan_block_reduce<V>(a0, red, dst, CVT, R, cv, tv, tr, vec, c);
+    if (noise) chan_block_reduce<V>(a1, red, dst + C, CVT, R, cv, tv, tr, vec, c);
+    if (y) chan_block_reduce<V>(a2, red, dst + 2 * C, CVT, R, cv, tv, tr, vec, c);
+}
+
+template <typename T, int V>
+__global__ void __launch_bounds__(TPB) scale_dot_k(const T* __restrict__ A, const T* __restrict__ B, const float* __restrict__ a,
+                                                   T* __restrict__ out, float* __restrict__ dot, int64_t HW, int C, int CVT, int R,
+                                                   int64_t rows_per_block) {
+    __shared__ float red[TPB * V];
+    const int tid = threadIdx.x;
+    const int tv = tid % CVT, tr = tid / CVT;
+    const int64_t n = blockIdx.y;
+    const int cv = C / V;
+    const int vec = blockIdx.z * CVT + tv;
+    const bool active = (tr < R) && (vec < cv);
+    const int c = vec * V;
+    float acc[V], sv[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+        acc[e] = 0.f;
+        sv[e] = active ? a[n * C + c + e] : 0.f;
+    }
+    if (active) {
+        const int64_t row0 = (int64_t)blockIdx.x * rows_per_block;
+        int64_t row1 = row0 + rows_per_block;
+        if (row1 > HW) row1 = HW;
+        for (int64_t row = row0 + tr; row < row1; row += R) {
+            const int64_t off = (n * HW + row) * C + c;
+            float g[V], xv[V], o[V];
+            load_f<T, V>(A + off, g);
+            load_f<T, V>(B + off, xv);
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                acc[e] = fmaf(g[e], xv[e], acc[e]);
+                o[e] = g[e] * sv[e];
+            }
+            store_f<T, V>(out + off, o);
+        }
+    }
+    chan_block_reduce<V>(acc, red, dot + n * C, CVT, R, cv, tv, tr, vec, c);
+}
+
+struct ChanGrid {
+    int V, CVT, R, zchunks;
+    int64_t bps, rpb;
+};
+template <typename T>
+static ChanGrid chan_grid(int N, int64_t HW, int C) {
+    ChanGrid g;
+    constexpr int VV = VecOf<T>::V;
+    g.V = (C % VV) == 0 ? VV : 1;
+    const int cv = C / g.V;
+    g.CVT = cv < TPB ? cv : TPB;
+    g.R = TPB / g.CVT;
+    g.zchunks = (cv + g.CVT - 1) / g.CVT;
+    int64_t bps = ceil_div64(HW, (int64_t)g.R * 4);
+    const int64_t cap = 8192 / ((int64_t)N * g.zchunks) > 0 ? 8192 / ((int64_t)N * g.zchunks) : 1;
+    if (bps > cap) bps = cap;
+    if (bps < 1) bps = 1;
+    int64_t rpb = ceil_div64(HW, bps);
+    rpb = ceil_div64(rpb, g.R) * g.R;
+    g.bps = ceil_div64(HW, rpb);
+    g.rpb = rpb;
+    return g;
+}
+
+template <typename T>
+static int modconv_bwd_pre_launch(const void* gy, const void* y, const void* noise, const float* dinv, float slope, void* gz,
+                                  float* sums, int N, int64_t HW, int C, hipStream_t st) {
+    const ChanGrid g = chan_grid<T>(N, HW, C);
+    GAN_CHECK_ARG(N <= 65535 && g.zchunks <= 65535, "modconv_bwd_pre: N or C too large for the grid");
+    dim3 grid((unsigned)g.bps, (unsigned)N, (unsigned)g.zchunks);
+    if (g.V > 1)
+        hipLaunchKernelGGL((modconv_bwd_pre_k<T, VecOf<T>::V>), grid, dim3(TPB), 0, st, (const T*)gy, (const T*)y, (const T*)noise, dinv,
+                           slope, (T*)gz, sums, HW, C, g.CVT, g.R, g.rpb);
+    else
+        hipLaunchKernelGGL((modconv_bwd_pre_k<T, 1>), grid, dim3(TPB), 0, st, (const T*)gy, (const T*)y, (const T*)noise, dinv, slope,
+                           (T*)gz, sums, HW, C, g.CVT, g.R, g.rpb);
+    GAN_CHECK_LAUNCH("modconv_bwd_pre");
+    return GAN_OK;
+}
+
+extern "C" int gan_modconv_bwd_pre(const void* gy, const void* y, const void* noise, const float* dinv, float slope, void* gz,
+                                   float* sums, int N, int64_t HW, int C, int dtype, gan_stream_t stream) {
+    GAN_CHECK_ARG(N >= 0 && HW >= 0 && C > 0, "modconv_bwd_pre: bad shape");
+    GAN_CHECK_ARG(sums && (N == 0 || HW == 0 || (gy && gz)), "modconv_bwd_pre: null pointer");
+    GAN_CHECK_ARG(dtype == GAN_F32 || dtype == GAN_BF16, "modconv_bwd_pre: bad dtype %d", dtype);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t bytes = sizeof(float) * (size_t)N * 3 * C;
+    if (bytes == 0) return GAN_OK;
+    if (hipMemsetAsync(sums, 0, bytes, st) != hipSuccess) {
+        gan_set_error("modconv_bwd_pre: memset failed");
+        return GAN_ERR_LAUNCH;
+    }
+    if (HW == 0) return GAN_OK;
+    if (dtype == GAN_F32) return modconv_bwd_pre_launch<float>(gy, y, noise, dinv, slope, gz, sums, N, HW, C, st);
+    return modconv_bwd_pre_launch<bf16>(gy, y, noise, dinv, slope, gz, sums, N, HW, C, st);
+}
+
+template <typename T>
+static int scale_dot_launch(const void* A, const void* B, const float* a, void* out, float* dot, int N, int64_t HW, int C,
+                            hipStream_t st) {
+    const ChanGrid g = chan_grid<T>(N, HW, C);
+    GAN_CHECK_ARG(N <= 65535 && g.zchunks <= 65535, "scale_dot: N or C too large for the grid");
+    dim3 grid((unsigned)g.bps, (unsigned)N, (unsigned)g.zchunks);
+    if (g.V > 1)
+        hipLaunchKernelGGL((scale_dot_k<T, VecOf<T>::V>), grid, dim3(TPB), 0, st, (const T*)A, (const T*)B, a, (T*)out, dot, HW, C, g.CVT,
+                           g.R, g.rpb);
+    else
+        hipLaunchKernelGGL((scale_dot_k<T, 1>), grid, dim3(TPB), 0, st, (const T*)A, (const T*)B, a, (T*)out, dot, HW, C, g.CVT, g.R, g.rpb);
+    GAN_CHECK_LAUNCH("scale_dot");
+    return GAN_OK;
+}
+
+extern "C" int gan_scale_dot(const void* A, const void* B, const float* a, void* out, float* dot, int N, int64_t HW, int C,
+                             int dtype, gan_stream_t stream) {
+    GAN_CHECK_ARG(N >= 0 && HW >= 0 && C > 0, "scale_dot: bad shape");
+    GAN_CHECK_ARG(dot && a && (N == 0 || HW == 0 || (A && B && out)), "scale_dot: null pointer");
+    GAN_CHECK_ARG(dtype == GAN_F32 || dtype == GAN_BF16, "scale_dot: bad dtype %d", dtype);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t bytes = sizeof(float) * (size_t)N * C;
+    if (bytes == 0) return GAN_OK;
+    if (hipMemsetAsync(dot, 0, bytes, st) != hipSuccess) {
+        gan_set_error("scale_dot: memset failed");
+        return GAN_ERR_LAUNCH;
+    }
+    if (HW == 0) return GAN_OK;
+    if (dtype == GAN_F32) return scale_dot_launch<float>(A, B, a, out, dot, N, HW, C, st);
+    return scale_dot_launch<bf16>(A, B, a, out, dot, N, HW, C, st);
+}
+
+// =========================================================================================
 // MinibatchStdDev statistic (reference: modelling/progressive_gan.py:25-36)
 // one workgroup per group column j; two-pass variance over the G members in registers.
 // =========================================================================================

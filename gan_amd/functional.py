@@ -234,6 +234,54 @@ def raw_chan_dot(A: Tensor, B: Optional[Tensor], b_mode: int, ymask: Optional[Te
     return out if per_sample else out.sum(0)
 
 
+def raw_modconv_bwd_pre(gy: Tensor, y: Optional[Tensor], noise: Optional[Tensor], dinv: Optional[Tensor], slope: float):
+    """One pass: gz = gy*m(y)*dinv and the per-sample sums (N, 3, C) [gy*m, gy*m*noise, gy*y] (include/gan_amd.h)."""
+    require_gpu(gy, y, noise, dinv)
+    lib = _lib.load()
+    gy = as_cl(gy.detach())
+    n, c, h, w = gy.shape
+    if y is not None:
+        y = as_cl(y.detach().to(gy.dtype))
+    if noise is not None:
+        noise = noise.detach().to(gy.dtype).reshape(n, h * w).contiguous()
+    d32, _ = _side(dinv, n, c, "modconv_bwd_pre dinv")
+    if d32 is not None and d32.numel() != n * c:
+        d32 = d32.reshape(1, c).expand(n, c).contiguous()
+    gz = _empty_like_cl(gy, gy.shape)
+    sums = torch.empty((n, 3, c), dtype=torch.float32, device=gy.device)
+    check(
+        _run(
+            "modconv_bwd_pre", 0, _nbytes(gy, y, noise, gz),
+            lambda: lib.gan_modconv_bwd_pre(ptr(gy), ptr(y), ptr(noise), ptr(d32), float(slope), ptr(gz), ptr(sums), n, h * w, c,
+                                            dtype_code(gy), stream_of(gy)),
+            (n, c, h, w),
+        ),
+        "gan_modconv_bwd_pre",
+    )
+    return gz, sums
+
+
+def raw_scale_dot(A: Tensor, B: Tensor, a: Tensor):
+    """One pass: out = A * a[n,c] and dot (N, C) = sum_hw A*B."""
+    require_gpu(A, B, a)
+    lib = _lib.load()
+    A = as_cl(A.detach())
+    B = as_cl(B.detach().to(A.dtype))
+    n, c, h, w = A.shape
+    a32 = _f32(a).reshape(n, c).contiguous()
+    out = _empty_like_cl(A, A.shape)
+    dot = torch.empty((n, c), dtype=torch.float32, device=A.device)
+    check(
+        _run(
+            "scale_dot", 0, _nbytes(A, B, out),
+            lambda: lib.gan_scale_dot(ptr(A), ptr(B), ptr(a32), ptr(out), ptr(dot), n, h * w, c, dtype_code(A), stream_of(A)),
+            (n, c, h, w),
+        ),
+        "gan_scale_dot",
+    )
+    return out, dot
+
+
 def _pad_channels(x: Tensor, mult: int) -> Tensor:
     c = x.shape[1]
     rem = (-c) % mult

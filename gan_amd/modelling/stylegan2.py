@@ -60,38 +60,36 @@ class ModConvFn(Function):
         gy = GF.as_cl(gy)
         n, cout = gy.shape[0], gy.shape[1]
         kh = weight.shape[2]
-        # ---- epilogue gradients: channel reductions over gy, masked by the activation output ----
+        # ---- one pass over (gy, y, noise): gz = gy * m(y) * dinv, the gradient entering the shared-weight
+        # convolution, and the three per-sample channel sums behind the bias / noise-scale / demodulation
+        # gradients ------------------------------------------------------------------------------------
         gb = gns = gdinv = None
-        mask = y if slope != 1.0 else None
-        want_dinv = dinv is not None and need[3]
-        t1 = t2 = None
-        if bias is not None and (need[4] or want_dinv):
-            t1 = GF.raw_chan_dot(gy, None, 0, mask, slope, True)  # sum_hw gy*m(y)  -> (N, Cout)
-            if need[4]:
-                gb = t1.sum(0).reshape(bias.shape).to(bias.dtype)
-        if ns is not None and (need[6] or want_dinv):
-            t2 = GF.raw_chan_dot(gy, noise, 2, mask, slope, True)  # sum_hw gy*m(y)*noise
-            if need[6]:
-                gns = t2.sum(0).reshape(ns.shape).to(ns.dtype)
-        if want_dinv:
+        gz, sums = GF.raw_modconv_bwd_pre(gy, y if slope != 1.0 else None, noise if ns is not None else None, dinv, slope)
+        if slope == 1.0 and dinv is not None and need[3]:  # no activation: the kernel had no y to form sum gy*y with
+            sums[:, 2] = GF.raw_chan_dot(gy, y, 1, None, 1.0, True)
+        t1, t2 = sums[:, 0], sums[:, 1]
+        if bias is not None and need[4]:
+            gb = t1.sum(0).reshape(bias.shape).to(bias.dtype)
+        if ns is not None and need[6]:
+            gns = t2.sum(0).reshape(ns.shape).to(ns.dtype)
+        if dinv is not None and need[3]:
             # z*dinv = lrelu^-1(y) - b - noise*ns   and   gy*m(y)*lrelu^-1(y) = gy*y
-            acc = GF.raw_chan_dot(gy, y, 1, None, 1.0, True)
-            if t1 is not None:
+            acc = sums[:, 2]
+            if bias is not None:
                 acc = acc - t1 * bias.detach().float().reshape(1, -1)
-            if t2 is not None:
+            if ns is not None:
                 acc = acc - t2 * ns.detach().float().reshape(1, -1)
             gdinv = (acc / dinv.detach().float()).reshape(dinv.shape).to(dinv.dtype)
-        # ---- gz = gy * m(y) * dinv: the gradient entering the shared-weight convolution ----------
-        gz = GF.raw_mask_scale(gy, y if slope != 1.0 else None, dinv, slope)
         gx = gw = gs = None
         if need[0] or need[2]:
-            gxs = GF.raw_conv2d_dgrad(gz, weight, pad, pad)  # d/d(U(x)*s), at the conv's input resolution
-            if up2:  # adjoint of nearest x2: sum each 2x2 block
-                h2, w2 = gxs.shape[2], gxs.shape[3]
-                gxs = GF.raw_upfirdn2d(gxs, torch.ones(2, 2, device=gxs.device), 1, 2, 0, 0, h2 // 2, w2 // 2)
-            if need[2]:
+            # d/d(U(x)*s); with U = nearest x2 its adjoint (the sum of each 2x2 block) rides on the accumulators
+            gxs = GF.raw_conv2d(gz, weight, kh - 1 - pad, kh - 1 - pad, transposed=True, pool=up2, gain=4.0 if up2 else 1.0)
+            if need[0] and need[2]:
+                gx, gs = GF.raw_scale_dot(gxs, x, s)  # one pass: dx = gxs * s and ds = sum_hw gxs * x
+                gs = gs.reshape(s.shape).to(s.dtype)
+            elif need[2]:
                 gs = GF.raw_chan_dot(gxs, x, 1, None, 1.0, True).reshape(s.shape).to(s.dtype)
-            if need[0]:
+            else:
                 gx = GF.raw_mask_scale(gxs, None, s, 1.0)
         if need[1]:
             gw = GF.raw_conv2d_wgrad(x, gz, kh, kh, pad, pad, up2=up2, in_scale=s).to(weight.dtype)

@@ -80,6 +80,17 @@ int gan_mask_scale(const void* g, const void* ymask, const float* a, int64_t a_s
 int gan_chan_dot(const void* A, const void* B, int b_mode, const void* ymask, float slope, float* out,
                  int64_t out_stride_n, int N, int64_t HW, int C, int dtype, gan_stream_t stream);
 
+/* Fused passes of the modulated convolution's backward (autograd of ModulatedConv2d.forward,
+ * modelling/stylegan2.py:29-36; they replace three gan_chan_dot calls + one gan_mask_scale, and one of each):
+ *   gan_modconv_bwd_pre: gz = gy * m(y) * dinv[n,c]                     (y, noise, dinv may be NULL)
+ *        sums[n][0][c] = sum_hw gy*m(y), sums[n][1][c] = sum_hw gy*m(y)*noise[n,hw], sums[n][2][c] = sum_hw gy*y
+ *        sums: fp32 [N][3][C], zeroed here (rows 1 / 2 stay zero without noise / y).
+ *   gan_scale_dot:       out = A * a[n,c],  dot[n][c] = sum_hw A*B       (dot: fp32 [N][C], zeroed here). */
+int gan_modconv_bwd_pre(const void* gy, const void* y, const void* noise, const float* dinv, float slope, void* gz,
+                        float* sums, int N, int64_t HW, int C, int dtype, gan_stream_t stream);
+int gan_scale_dot(const void* A, const void* B, const float* a, void* out, float* dot, int N, int64_t HW, int C, int dtype,
+                  gan_stream_t stream);
+
 /* ---- implicit-GEMM convolution (MFMA) ----------------------------------------------------
  * replaces ModulatedConv2d.forward / batched_conv2d   modelling/stylegan2.py:18-36
  *          nn.Conv2d of the discriminator             modelling/progressive_gan.py:45-50,61,72,74
