@@ -42,6 +42,8 @@ _SIGNATURES = {
     "gan_conv2d_wgrad": (c_int, [c_void_p] * 4 + [c_int] * 12 + [c_void_p, c_int64, c_float, c_int, c_float, c_int, c_void_p]),
     "gan_modconv_bwd_pre": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_void_p]),
     "gan_scale_dot": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_void_p]),
+    "gan_demod_fwd": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p]),
+    "gan_demod_bwd": (c_int, [c_void_p] * 7 + [c_int] * 4 + [c_void_p]),
     "gan_pack_weight": (c_int, [c_void_p, c_int, c_void_p, c_int] + [c_int] * 7 + [c_void_p]),
     "gan_mbstd_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_int, c_void_p]),
     "gan_ema_lerp": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_void_p]),

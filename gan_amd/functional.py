@@ -339,9 +339,13 @@ def _wide_kernel_shape(x: Tensor, cin_p: int, cout: int, ho: int, wo: int, kh: i
     """Mirror of the C-side dispatch (conv_fwd.hip: thin kernel first, then conv_wide.hip's eligibility)."""
     if x.dtype != torch.bfloat16 or cin_p % 64 != 0 or cout % 4 != 0 or x.shape[0] * ho * wo < 128:
         return False
-    thin = (kh == kw and kh in (1, 3) and py == px == (kh - 1) // 2 and cin_p in (8, 16, 32, 64) and cout <= 64
-            and wo >= 32 and ho >= 8)
-    return not thin
+    return not _thin_kernel_shape(x, cin_p, cout, ho, wo, kh, kw, py, px)
+
+
+def _thin_kernel_shape(x: Tensor, cin_p: int, cout: int, ho: int, wo: int, kh: int, kw: int, py: int, px: int) -> bool:
+    """Shapes conv_thin.hip serves (HBM-bound direct convolution); used to pick the profile family too."""
+    return (x.dtype == torch.bfloat16 and kh == kw and kh in (1, 3) and py == px == (kh - 1) // 2
+            and cin_p in (8, 16, 32, 64) and cout <= 64 and wo >= 32 and ho >= 8)
 
 
 def raw_conv2d(
@@ -410,9 +414,15 @@ def raw_conv2d(
             raise _lib.GanAmdError(f"conv2d: aux shape {tuple(aux.shape)} != output shape {(n, cout, hy, wy)}")
         aux = as_cl(aux.detach().to(x.dtype))
     y = _empty_like_cl(x, (n, cout, hy, wy))
+    if _thin_kernel_shape(x, cin_p, cout, ho, wo, kh, kw, py, px):
+        family = "conv2d_fwd_thin"  # HBM-bound
+    elif in_scale is None and in_slope == 1.0 and _wide_kernel_shape(x, cin_p, cout, ho, wo, kh, kw, py, px):
+        family = "conv2d_fwd_wide"  # MFMA-bound, LDS-DMA implicit GEMM
+    else:
+        family = "conv2d_fwd"
     check(
         _run(
-            "conv2d_fwd", 2.0 * n * ho * wo * cout * cin * kh * kw, _nbytes(x, y, wt, noise, aux),
+            family, 2.0 * n * ho * wo * cout * cin * kh * kw, _nbytes(x, y, wt, noise, aux),
             lambda: lib.gan_conv2d_fwd(
                 ptr(x), ptr(wt), ptr(y), ptr(in_scale), ptr(out_scale32), ptr(bias32), ptr(noise), ptr(ns32), float(slope),
                 n, h, w, cin_p, int(up2), ho, wo, cout, kh, kw, py, px, kpad,
@@ -463,9 +473,11 @@ def raw_conv2d_wgrad(
     # allocator hands the same block back every step
     ws_floats = lib.gan_conv2d_wgrad_workspace(n, h, w, cin_p, int(up2), ho, wo, cout_p, kh, kw, py, px, dtype_code(x))
     ws = torch.empty((ws_floats,), dtype=torch.float32, device=x.device) if ws_floats > 0 else None
+    thin_w = (x.dtype == torch.bfloat16 and kh == kw and kh in (1, 3) and py == px == (kh - 1) // 2 and cin_p <= 64
+              and cout_p <= 64 and wo >= 32 and ho >= 8)
     check(
         _run(
-            "conv2d_wgrad", 2.0 * n * ho * wo * cout * cin * kh * kw, _nbytes(x, gy, dw),
+            "conv2d_wgrad_thin" if thin_w else "conv2d_wgrad", 2.0 * n * ho * wo * cout * cin * kh * kw, _nbytes(x, gy, dw),
             lambda: lib.gan_conv2d_wgrad(
                 ptr(x), ptr(gy), ptr(dw), ptr(in_scale), n, h, w, cin_p, int(up2), ho, wo, cout_p, kh, kw, py, px,
                 ptr(ws), ws_floats, float(x_slope), int(pooled), 0.25 if pooled else 1.0, dtype_code(x), stream_of(x)
@@ -813,6 +825,50 @@ class ConvBiasActFn(Function):
 
 def conv_bias_act(x: Tensor, weight: Tensor, bias: Optional[Tensor], padding: int, slope: float = 1.0, in_slope: float = 1.0) -> Tensor:
     return ConvBiasActFn.apply(x, weight, bias, padding, slope, in_slope)
+
+
+class DemodFn(Function):
+    """dinv (N, Cout) = 1 / max(||W * s[n]||_(ci,kh,kw), 1e-8): the demodulation factor of ModulatedConv2d
+    (stylegan2.py:33) from s (N, Cin) and W (Cout, Cin, kh, kw), fp32, two launches forward and two backward
+    (kernels gan_demod_fwd / gan_demod_bwd).  Under create_graph the backward is the same formula written with
+    tensor ops on the inputs, so it can be differentiated again."""
+
+    @staticmethod
+    def forward(ctx, s, weight):
+        require_gpu(s, weight)
+        lib = _lib.load()
+        s32 = s.detach().float().contiguous()
+        w32 = weight.detach().float().contiguous()
+        n, cin = s32.shape
+        cout, taps = w32.shape[0], w32.shape[2] * w32.shape[3]
+        wsq = torch.empty((cout, cin), dtype=torch.float32, device=s.device)
+        dinv = torch.empty((n, cout), dtype=torch.float32, device=s.device)
+        check(lib.gan_demod_fwd(ptr(s32), ptr(w32), ptr(wsq), ptr(dinv), n, cin, cout, taps, stream_of(s32)), "gan_demod_fwd")
+        ctx.save_for_backward(s, weight, wsq, dinv)
+        return dinv
+
+    @staticmethod
+    def backward(ctx, g):
+        s, weight, wsq, dinv = ctx.saved_tensors
+        if torch.is_grad_enabled():
+            sf, wf = s.float(), weight.float()
+            wsq_t = wf.square().sum(dim=(2, 3))                                   # (Cout, Cin)
+            d = (sf.square() @ wsq_t.t()).rsqrt()                                  # (N, Cout)
+            dq = torch.where(d < 1e8, -0.5 * d * d * d * g.float(), torch.zeros_like(d))
+            gs = (2.0 * sf * (dq @ wsq_t)).to(s.dtype) if _need(ctx, 0) else None
+            gw = (2.0 * wf * (dq.t() @ sf.square())[:, :, None, None]).to(weight.dtype) if _need(ctx, 1) else None
+            return gs, gw
+        lib = _lib.load()
+        s32 = s.detach().float().contiguous()
+        w32 = weight.detach().float().contiguous()
+        n, cin = s32.shape
+        cout, taps = w32.shape[0], w32.shape[2] * w32.shape[3]
+        g = g.detach().float().contiguous()
+        gs = torch.empty_like(s32) if _need(ctx, 0) else None
+        gw = torch.empty_like(w32) if _need(ctx, 1) else None
+        check(lib.gan_demod_bwd(ptr(g), ptr(dinv), ptr(s32), ptr(w32), ptr(wsq), ptr(gs), ptr(gw), n, cin, cout, taps, stream_of(g)),
+              "gan_demod_bwd")
+        return (gs.to(s.dtype) if gs is not None else None), (gw.to(weight.dtype) if gw is not None else None)
 
 
 def minibatch_stddev_stat(x: Tensor, group: int) -> Tensor:

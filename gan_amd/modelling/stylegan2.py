@@ -138,15 +138,22 @@ class ModulatedConv2d(nn.Conv2d):
         self.style_weight = nn.Linear(z_dim, in_channels)  # A in the paper
         self.demodulation = demodulation
 
+    _styles = None  # (N, Cin) set by StyleGan2Generator.forward: every layer's A(w) + 1 from ONE GEMM
+
     def style_and_demod(self, w: Tensor):
         """s = A(w) + 1 (stylegan2.py:30) and the demodulation factor of F.normalize(dim=(2,3,4),
-        eps=1e-8) (stylegan2.py:33), both in fp32: two tiny GEMMs instead of an (N,Cout,Cin,k,k) tensor."""
+        eps=1e-8) (stylegan2.py:33), both in fp32, never forming the (N,Cout,Cin,k,k) tensor."""
         with torch.autocast("cuda", enabled=False):
-            s = F.linear(w.float(), self.style_weight.weight, self.style_weight.bias) + 1  # (N, Cin)
+            s, self._styles = self._styles, None
+            if s is None:
+                s = F.linear(w.float(), self.style_weight.weight, self.style_weight.bias) + 1  # (N, Cin)
             dinv = None
             if self.demodulation:
-                wsq = self.weight.float().square().sum(dim=(2, 3))  # (Cout, Cin)
-                dinv = 1.0 / (s.square() @ wsq.t()).sqrt().clamp_min(1e-8)  # (N, Cout)
+                if s.is_cuda:
+                    dinv = GF.DemodFn.apply(s, self.weight)  # (N, Cout)
+                else:
+                    wsq = self.weight.float().square().sum(dim=(2, 3))  # (Cout, Cin)
+                    dinv = 1.0 / (s.square() @ wsq.t()).sqrt().clamp_min(1e-8)
         return s, dinv
 
     def fused(self, x: Tensor, w: Tensor, noise: Optional[Tensor], noise_scale: Optional[Tensor], slope: float, up2: bool):
@@ -227,9 +234,22 @@ class StyleGan2Generator(nn.Module):
     def reset_parameters(self):
         self.apply(init_weights)
 
+    def _all_styles(self, w: Tensor) -> None:
+        """Every ModulatedConv2d's style s = A_l(w) + 1 (stylegan2.py:30) from one GEMM over the stacked A_l:
+        all layers see the same w (no style mixing, stylegan2.py:93-99), and 20 separate (N,128)x(128,Cin)
+        products are 20 latency-bound launches forward and 40 backward."""
+        mods = [m for m in self.modules() if isinstance(m, ModulatedConv2d)]
+        with torch.autocast("cuda", enabled=False):
+            a_all = torch.cat([m.style_weight.weight for m in mods], 0)
+            b_all = torch.cat([m.style_weight.bias for m in mods], 0)
+            s_all = F.linear(w.float(), a_all, b_all) + 1
+            for m, s in zip(mods, torch.split(s_all, [m.in_channels for m in mods], dim=1)):
+                m._styles = s.contiguous()
+
     def forward(self, z: Tensor) -> Tensor:
         # mapping network: 8 x (128x128 Linear + LeakyReLU) on (N,128) -- plain library GEMMs (hipBLASLt)
         w = self.mapping_network(z)
+        self._all_styles(w)
         dt = GF.act_dtype(z)
         x = self.learned_input.to(dt).expand(z.shape[0], -1, -1, -1)
         x, y = self.blocks[0](x, w)

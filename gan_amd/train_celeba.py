@@ -16,6 +16,7 @@ from typing import Callable, Dict, Iterator, List, Optional
 import torch
 from torch import Tensor, nn
 
+from . import functional as GF
 from .distributed import GradBucketReducer, init_from_env, interleaved_shard
 from .losses import get_loss, get_regularizer
 from .modelling import build_discriminator, build_generator
@@ -50,6 +51,10 @@ class TrainConfig:
     log_img_interval: int = 1_000
     fid_interval: int = 5_000
 
+    # MI355X-side knobs (no counterpart in the reference's TrainConfig): replay the iteration as one HIP graph
+    hip_graph: bool = False
+    graph_warmup: int = 3
+
 
 def _fix_betas(kwargs: dict) -> dict:
     """README.md:60 passes betas [0, 0.9]; recent torch.optim.Adam rejects the int 0."""
@@ -83,6 +88,11 @@ class Trainer:
         self.regularizer = get_regularizer(cfg.regularizer)
         optim_cls = getattr(torch.optim, cfg.optimizer)
         okw = _fix_betas(cfg.optimizer_kwargs)
+        if cfg.hip_graph and cfg.optimizer in ("Adam", "AdamW"):
+            okw = dict(okw, capturable=True)  # step counters live on the device: the optimizer step can be captured
+        self._graph = None
+        self._graph_reals: List[Tensor] = []
+        self._graph_logs: Optional[Dict[str, Tensor]] = None
         self.optim_d = optim_cls(self.disc.parameters(), cfg.lr, **okw)
         self.optim_g = optim_cls(self.gen.parameters(), cfg.lr, **okw)
         self.autocast_ctx = lambda: torch.autocast(self.device.type, dtype=torch.bfloat16, enabled=cfg.mixed_precision)
@@ -97,7 +107,44 @@ class Trainer:
 
     def train_step(self, next_reals: Callable[[], Tensor]) -> Dict[str, Tensor]:
         """One generator iteration = the `while` body of train_celeba.py:111-149.  `next_reals()` returns
-        this rank's (local_batch // grad_accum, 3, S, S) real images, already on the device."""
+        this rank's (local_batch // grad_accum, 3, S, S) real images, already on the device.
+
+        With cfg.hip_graph (single process only) the whole iteration except the EMA update -- both forward /
+        backward passes, R1, both optimizer steps: ~2600 kernel launches -- is captured once into a HIP graph
+        after `graph_warmup` eager iterations and replayed from then on: the launches cost no host time and
+        the GPU no idle gaps between them.  The EMA weight follows a host-side schedule (utils.py:85-96), so
+        that one launch stays outside the graph."""
+        if self.cfg.hip_graph and self.world == 1:
+            logs = self._graph_step(next_reals)
+        else:
+            logs = self._iteration(next_reals)
+        self.gen_ema.step()
+        self.step += 1
+        return logs
+
+    def _graph_step(self, next_reals: Callable[[], Tensor]) -> Dict[str, Tensor]:
+        cfg = self.cfg
+        if self._graph is None:
+            if self.step < cfg.graph_warmup:
+                return self._iteration(next_reals)
+            n_fetch = cfg.n_disc * cfg.grad_accum
+            self._graph_reals = [next_reals().clone() for _ in range(n_fetch)]
+            GF._PACK_CACHE.clear()  # every packed weight the graph reads must be packed inside it
+            feed = iter(self._graph_reals)
+            graph = torch.cuda.CUDAGraph()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(graph):
+                self._graph_logs = self._iteration(lambda: next(feed).detach())  # an alias: requires_grad_ stays off the buffer
+            self._graph = graph
+            # the capture pass does not execute: run the iteration it recorded on the data it fetched
+        else:
+            for buf in self._graph_reals:
+                buf.copy_(next_reals())
+        self._graph.replay()
+        GF._PACK_CACHE.clear()  # a replay updates the weights without bumping their Python-side versions
+        return {k: v.clone() for k, v in self._graph_logs.items()}
+
+    def _iteration(self, next_reals: Callable[[], Tensor]) -> Dict[str, Tensor]:
         cfg, disc, gen = self.cfg, self.disc, self.gen
         for i in range(cfg.n_disc):
             cached_reals: Optional[List[Tensor]] = [] if i == cfg.n_disc - 1 else None
@@ -142,8 +189,6 @@ class Trainer:
         self.optim_g.step()
         self.red_g.zero_grad()
         disc.requires_grad_(True)
-        self.gen_ema.step()
-        self.step += 1
         # tensors, not floats: no host sync here (the reference syncs every 50 steps, train_celeba.py:153-160)
         return {"loss/d": loss_d.detach(), "d/real": d_reals.detach().mean(), "d/fake": d_fakes.detach().mean(), "loss/g": loss_g.detach()}
 

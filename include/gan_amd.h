@@ -91,6 +91,16 @@ int gan_modconv_bwd_pre(const void* gy, const void* y, const void* noise, const 
 int gan_scale_dot(const void* A, const void* B, const float* a, void* out, float* dot, int N, int64_t HW, int C, int dtype,
                   gan_stream_t stream);
 
+/* Demodulation factor of ModulatedConv2d: replaces F.normalize(weight * s, dim=(2,3,4), eps=1e-8)
+ * (modelling/stylegan2.py:33) by dinv[n][co] = 1 / max(sqrt(sum_ci s[n,ci]^2 * wsq[co,ci]), 1e-8),
+ * wsq[co][ci] = sum_taps W^2 (written here: a [Cout][Cin] scratch the caller owns and hands back to the
+ * backward).  All fp32; s: [N][Cin], w: [Cout][Cin][taps].  Backward: gs [N][Cin] and / or gw [Cout][Cin][taps]
+ * (either may be NULL) from g = d loss / d dinv. */
+int gan_demod_fwd(const float* s, const float* w, float* wsq, float* dinv, int N, int Cin, int Cout, int taps,
+                  gan_stream_t stream);
+int gan_demod_bwd(const float* g, const float* dinv, const float* s, const float* w, const float* wsq, float* gs,
+                  float* gw, int N, int Cin, int Cout, int taps, gan_stream_t stream);
+
 /* ---- implicit-GEMM convolution (MFMA) ----------------------------------------------------
  * replaces ModulatedConv2d.forward / batched_conv2d   modelling/stylegan2.py:18-36
  *          nn.Conv2d of the discriminator             modelling/progressive_gan.py:45-50,61,72,74

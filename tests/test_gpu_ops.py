@@ -545,3 +545,25 @@ def test_conv2d_wide_kernel(dev, case):
     got2 = GF.raw_conv2d(x.to(dev), wgt.to(dev), pad, pad, up2=up2, bias=b.to(dev), in_slope=0.2, pool=pool,
                          aux=aux.to(dev), aux_slope=0.2, gain=0.25)
     assert rel_err(got2, ref2) < 4e-3, rel_err(got2, ref2)
+
+
+@pytest.mark.parametrize("shape", [(4, 16, 24, 3), (7, 512, 512, 3), (256, 33, 5, 1), (3, 64, 128, 3)])
+def test_demod_kernels(dev, shape):
+    """gan_demod_fwd / gan_demod_bwd against F.normalize's norm (stylegan2.py:33) differentiated by torch in fp64."""
+    import gan_amd.functional as GF
+
+    n, cin, cout, k = shape
+    torch.manual_seed(41)
+    s = torch.randn(n, cin) * 0.5 + 1
+    w = torch.randn(cout, cin, k, k) / (cin * k * k) ** 0.5
+    s_ref = s.double().requires_grad_(True)
+    w_ref = w.double().requires_grad_(True)
+    ref = 1.0 / (w_ref.unsqueeze(0) * s_ref.view(n, 1, cin, 1, 1)).flatten(2).norm(dim=2).clamp_min(1e-8)
+    cot = torch.randn(n, cout)
+    gs_ref, gw_ref = torch.autograd.grad((ref * cot.double()).sum(), [s_ref, w_ref])
+    sg = s.to(dev).requires_grad_(True)
+    wg = w.to(dev).requires_grad_(True)
+    got = GF.DemodFn.apply(sg, wg)
+    assert rel_err(got, ref) < TOL32
+    gs, gw = torch.autograd.grad((got * cot.to(dev)).sum(), [sg, wg])
+    assert rel_err(gs, gs_ref) < TOL32 and rel_err(gw, gw_ref) < TOL32
