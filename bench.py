@@ -34,6 +34,10 @@ import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16
+# profile family (gan_amd/functional.py) -> device kernel; the first three are priced against the MFMA peak
+MFMA_FAMILIES = {"conv2d_fwd_wide128": "conv_wide_k<128>", "conv2d_fwd_wide64": "conv_wide_k<64>",
+                 "conv2d_fwd": "conv_fwd_k<...>", "conv2d_wgrad": "conv_wgrad_tiled_k<...> / conv_wgrad_k<...>"}
+HBM_FAMILIES = {"conv2d_fwd_thin": "conv_thin_k<...>", "conv2d_wgrad_thin": "conv_thin_wgrad_k<...>"}
 
 
 def parse():
@@ -94,25 +98,27 @@ def roofline_leg(trainer, next_reals):
     fams = {}
     for name, d in table.items():
         sec = d["ms"] * 1e-3
+        mfma = bool(d["flops"]) and name in MFMA_FAMILIES
         fams[name] = dict(
             launches=d["launches"], ms=round(d["ms"], 3), share=round(d["ms"] / total_ms, 4),
             tflops=round(d["flops"] / sec / 1e12, 2) if d["flops"] else None,
-            gbs=round(d["bytes"] / sec / 1e9, 1),
+            gbs=round(d["bytes"] / sec / 1e9, 1), bound="mfma" if mfma else "hbm",
+            frac=round(d["flops"] / sec / 1e12 / MFMA_BF16_PEAK_TFLOPS if mfma else d["bytes"] / sec / 1e9 / HBM_PEAK_GBS, 4),
         )
     dom = max(table, key=lambda k: table[k]["ms"])
     d = table[dom]
     sec = d["ms"] * 1e-3
     # MFMA-bound families: the wide-layer implicit GEMMs and weight gradients; everything else (thin-layer
     # convolutions at 144..576 MACs per output element, FIR, pointwise, reductions) is priced against HBM
-    if d["flops"] and dom in ("conv2d_fwd_wide", "conv2d_fwd", "conv2d_wgrad"):
+    if d["flops"] and dom in MFMA_FAMILIES:
         ach = d["flops"] / sec / 1e12
-        roof = dict(kernel=dom, bound="mfma", achieved=round(ach, 2), peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s",
+        roof = dict(kernel=dom, symbol=MFMA_FAMILIES[dom], bound="mfma", achieved=round(ach, 2), peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s",
                     frac=round(ach / MFMA_BF16_PEAK_TFLOPS, 4), traffic=None,
                     launches=d["launches"], avg_launch_us=round(d["ms"] * 1e3 / d["launches"], 2),
                     hbm_gbs=round(d["bytes"] / sec / 1e9, 1))
     else:
         ach = d["bytes"] / sec / 1e9
-        roof = dict(kernel=dom, bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+        roof = dict(kernel=dom, symbol=("conv_thin_k" + dom[len("conv2d_fwd_thin"):] if dom.startswith("conv2d_fwd_thin") else HBM_FAMILIES.get(dom, dom + "_k")), bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(ach / HBM_PEAK_GBS, 4), traffic=None,
                     launches=d["launches"], avg_launch_us=round(d["ms"] * 1e3 / d["launches"], 2))
     return roof, fams

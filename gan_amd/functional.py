@@ -415,9 +415,11 @@ def raw_conv2d(
         aux = as_cl(aux.detach().to(x.dtype))
     y = _empty_like_cl(x, (n, cout, hy, wy))
     if _thin_kernel_shape(x, cin_p, cout, ho, wo, kh, kw, py, px):
-        family = "conv2d_fwd_thin"  # HBM-bound
+        # HBM-bound; one family per device kernel instantiation conv_thin_k<CIN, COUT, KS, RPW, MODE, VEC>
+        mode = "G" if (in_scale is not None or out_scale is not None or noise is not None) else ("DP" if pool else ("DA" if aux is not None else "D"))
+        family = f"conv2d_fwd_thin<{cin_p},{16 if cout <= 16 else (32 if cout <= 32 else 64)},{kh},{mode}>"
     elif in_scale is None and in_slope == 1.0 and _wide_kernel_shape(x, cin_p, cout, ho, wo, kh, kw, py, px):
-        family = "conv2d_fwd_wide"  # MFMA-bound, LDS-DMA implicit GEMM
+        family = "conv2d_fwd_wide128" if cout > 64 else "conv2d_fwd_wide64"  # MFMA-bound: conv_wide_k<128> / <64>
     else:
         family = "conv2d_fwd"
     check(
