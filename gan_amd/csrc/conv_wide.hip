@@ -12,7 +12,7 @@
 //     falls outside the image (zero padding) or past M / Cout get an out-of-range buffer offset and the
 //     hardware writes zeros.  Nearest-2x upsampling is part of the address;
 //   * the LDS image of a wave instruction is lane-linear (8 rows x 128 B), so the bank swizzle is applied on
-//     the SOURCE side: slot `pos` of row r holds chunk pos ^ (r & 7); fragment reads use the same XOR;
+//     the SOURCE side: slot `pos` of row r holds chunk pos ^ ((r >> 1) & 7); fragment reads use the same XOR;
 //   * two LDS stages; the DMA of step s+1 is in flight while step s is on the matrix cores;
 //   * operand roles are swapped (A = weights, B = pixels) so a lane owns 4 consecutive output channels of one
 //     pixel: 8-byte stores, and with the pooled row order (2x2 window = 4 consecutive rows = 4 adjacent
@@ -43,6 +43,54 @@ struct WideArgs {
     unsigned x_bytes, w_bytes, y_bytes;
 };
 
+// buffer offsets of this lane's four pixel rows for tap (dy, dx): recomputed once per tap, not per K step
+__device__ __forceinline__ void wide_set_tap(unsigned (&va)[4], const int (&a_n)[4], const int (&a_yx)[4], int dy, int dx, int csrc,
+                                             const WideArgs& p) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int iy = (a_yx[j] >> 16) + dy - p.py;
+        const int ix = (a_yx[j] & 0xffff) + dx - p.px;
+        const bool ok = a_n[j] >= 0 && (unsigned)iy < (unsigned)p.Hl && (unsigned)ix < (unsigned)p.Wl;
+        const unsigned off = (unsigned)(((a_n[j] * p.H + (iy >> p.up2)) * p.W + (ix >> p.up2)) * p.Cin + csrc * 8) * 2u;
+        va[j] = ok ? off : WIDE_INV;
+    }
+}
+
+// the K step the next wide_issue() stages, and this lane's row offsets for its tap
+struct WideCursor {
+    unsigned va[4];
+    int tap, cb, dy, dx;
+};
+
+// LDS-DMA of one K step (64 channels of one tap) into stage `buf`, then advance the cursor
+template <int BN>
+__device__ __forceinline__ void wide_issue(WideCursor& cur, char* lds, int buf, int wave, __amdgpu_buffer_rsrc_t rx,
+                                           __amdgpu_buffer_rsrc_t rw, const unsigned (&b_off)[BN / 32], const int (&a_n)[4],
+                                           const int (&a_yx)[4], int csrc, const WideArgs& p) {
+    constexpr int A_BYTES = 128 * 128, STAGE = A_BYTES + BN * 128;
+    char* const A = lds + buf * STAGE;
+    char* const B = A + A_BYTES;
+    const int soa = cur.cb * 2, sob = (cur.tap * p.Cin + cur.cb) * 2;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(A + (4 * j + wave) * 1024), 16, cur.va[j], soa,
+                                                 0, 0);
+#pragma unroll
+    for (int j = 0; j < BN / 32; ++j)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(B + (4 * j + wave) * 1024), 16, b_off[j], sob, 0,
+                                                 0);
+    cur.cb += 64;
+    if (cur.cb == p.Cin) {  // wave-uniform: next tap
+        cur.cb = 0;
+        ++cur.tap;
+        if (++cur.dx == p.kw) {
+            cur.dx = 0;
+            ++cur.dy;
+        }
+        wide_set_tap(cur.va, a_n, a_yx, cur.dy, cur.dx, csrc, p);
+    }
+}
+
 template <int BN>
 __global__ void __launch_bounds__(256, 2) conv_wide_k(const WideArgs p) {
     constexpr int BM = 128, FP = 4, FC = BN / 32;          // wave tile: 64 pixels x BN/2 channels
@@ -60,7 +108,11 @@ __global__ void __launch_bounds__(256, 2) conv_wide_k(const WideArgs p) {
 
     // ---- staging bookkeeping: wave instruction j covers rows (4j + wave)*8 .. +7, 8 lanes per row ----------
     const int rsub = lane >> 3;
-    const int csrc = (lane & 7) ^ rsub;  // source chunk of this lane's LDS slot
+    // source chunk of this lane's LDS slot: pos ^ ((row >> 1) & 7).  A fragment read touches 16 consecutive rows
+    // per 16 lanes; two rows span all 64 banks, so the key must be distinct for the 8 row PAIRS (keyed on
+    // row & 7 the rows r and r+8 collided: 2-way conflicts on every ds_read_b128 of a kernel that moves
+    // 128 B/clk through LDS at full MFMA rate).  Row = (4j + wave)*8 + rsub  =>  (row >> 1) & 7 = (wave&1)*4 + rsub/2.
+    const int csrc = (lane & 7) ^ (((wave & 1) << 2) | (rsub >> 1));
     int a_n[4], a_yx[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -89,30 +141,12 @@ __global__ void __launch_bounds__(256, 2) conv_wide_k(const WideArgs p) {
         b_off[j] = co < p.Cout ? (unsigned)(co * p.Kpad + csrc * 8) * 2u : WIDE_INV;
     }
 
-    auto issue = [&](int s, int buf) {
-        const int k0 = s * 64;
-        const int tap = k0 / p.Cin;
-        const int cb = k0 - tap * p.Cin;
-        const int dy = tap / p.kw;
-        const int dx = tap - dy * p.kw;
-        char* const A = lds + buf * STAGE;
-        char* const B = A + A_BYTES;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int iy = (a_yx[j] >> 16) + dy - p.py;
-            const int ix = (a_yx[j] & 0xffff) + dx - p.px;
-            const bool ok = a_n[j] >= 0 && (unsigned)iy < (unsigned)p.Hl && (unsigned)ix < (unsigned)p.Wl;
-            const unsigned off = (unsigned)(((a_n[j] * p.H + (iy >> p.up2)) * p.W + (ix >> p.up2)) * p.Cin + cb + csrc * 8) * 2u;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(A + (4 * j + wave) * 1024), 16,
-                                                     ok ? off : WIDE_INV, 0, 0, 0);
-        }
-#pragma unroll
-        for (int j = 0; j < BN / 32; ++j) {
-            const unsigned off = b_off[j] == WIDE_INV ? WIDE_INV : b_off[j] + (unsigned)k0 * 2u;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(B + (4 * j + wave) * 1024), 16, off, 0,
-                                                     0, 0);
-        }
-    };
+    // Per-lane source offsets change only when the K loop moves to the next tap; the channel block inside a tap
+    // (and the k offset of the weight rows) is wave-uniform and rides in the instruction's scalar offset, so a
+    // K step costs no address VALU at all.  (PMC before: 144 VALU instructions per step against 32 MFMAs.)
+    WideCursor cur;
+    cur.tap = cur.cb = cur.dy = cur.dx = 0;
+    wide_set_tap(cur.va, a_n, a_yx, 0, 0, csrc, p);
 
     f32x4 acc[FC][FP];
 #pragma unroll
@@ -121,18 +155,18 @@ __global__ void __launch_bounds__(256, 2) conv_wide_k(const WideArgs p) {
         for (int f = 0; f < FP; ++f) acc[i][f] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int frow = lane & 15, fq = lane >> 4;
-    // byte offset of this lane's fragment chunk (k half h) inside a 128-byte row r: ((4h + fq) ^ (r & 7)) * 16;
-    // r & 7 == frow & 7 for every fragment row (tile offsets are multiples of 16)
-    const int sw0 = ((fq) ^ (frow & 7)) << 4, sw1 = ((4 + fq) ^ (frow & 7)) << 4;
+    // byte offset of this lane's fragment chunk (k half h) inside a 128-byte row r: ((4h + fq) ^ ((r >> 1) & 7)) * 16;
+    // (r >> 1) & 7 == frow >> 1 for every fragment row (tile offsets are multiples of 16)
+    const int sw0 = ((fq) ^ (frow >> 1)) << 4, sw1 = ((4 + fq) ^ (frow >> 1)) << 4;
     const int xrow = (wm * 64 + frow) * 128, wrow = (wn * (BN / 2) + frow) * 128;
 
-    issue(0, 0);
+    wide_issue<BN>(cur, lds, 0, wave, rx, rw, b_off, a_n, a_yx, csrc, p);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     for (int s = 0; s < p.ksteps; ++s) {
         const int buf = s & 1;
-        if (s + 1 < p.ksteps) issue(s + 1, buf ^ 1);
+        if (s + 1 < p.ksteps) wide_issue<BN>(cur, lds, buf ^ 1, wave, rx, rw, b_off, a_n, a_yx, csrc, p);
         const char* const A = lds + buf * STAGE;
         const char* const B = A + A_BYTES;
 #pragma unroll
