@@ -275,7 +275,7 @@ int launch_thin_w(ThinWArgs a, int64_t ws_floats, int64_t* need, hipStream_t st)
 template <int CIN, int COUT>
 int pick_ks(const ThinWArgs& a, int ks, int64_t wsf, int64_t* need, hipStream_t st) {
     constexpr int F = (CIN / 16) * (COUT / 16);
-    constexpr int TH = (CIN <= 16 && COUT <= 32) ? 16 : 8;
+    constexpr int TH = (CIN <= 16 && COUT <= 16) ? 16 : 8;
     if (ks == 1) return launch_thin_w<CIN, COUT, 1, TH, 1>(a, wsf, need, st);
     constexpr int WT = F <= 2 ? 1 : (F <= 8 ? 2 : 4);
     return launch_thin_w<CIN, COUT, 3, TH, WT>(a, wsf, need, st);

@@ -34,13 +34,18 @@ def init_from_env(device_type: Optional[str] = None) -> Tuple[int, int, torch.de
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     use_gpu = (device_type or ("cuda" if torch.cuda.is_available() else "cpu")) == "cuda"
+    # GAN_AMD_ONE_GPU=1 (rehearsal aid): every rank uses cuda:0 and the collectives go over gloo, so the
+    # multi-process path can be exercised on a single-GPU box; RCCL needs one device per rank
+    one_gpu = use_gpu and os.environ.get("GAN_AMD_ONE_GPU") == "1"
+    if one_gpu:
+        local = 0
     device = torch.device("cuda", local) if use_gpu else torch.device("cpu")
     if use_gpu:
         torch.cuda.set_device(device)
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        if use_gpu:
+        if use_gpu and not one_gpu:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -69,6 +74,9 @@ class GradBucketReducer:
     def __init__(self, module: nn.Module, bucket_bytes: int = 8 << 20, group=None):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # GAN_AMD_FORCE_ALLREDUCE=1 (test aid): issue the bucket all-reduces in a 1-rank group too, so the RCCL
+        # calls, their hooks and the stream hand-over run on a single-GPU box
+        self._force = dist.is_initialized() and os.environ.get("GAN_AMD_FORCE_ALLREDUCE") == "1"
         self.arena: FlatArena = arena_of(module, with_grad=True)
         self.arena.attach_grads()
         self.buckets: List[Tuple[int, int, List[int]]] = []  # (start, end, param indices)
@@ -110,7 +118,7 @@ class GradBucketReducer:
         if self._fired[b]:
             return
         self._fired[b] = True
-        if self.world == 1:
+        if self.world == 1 and not self._force:
             return
         start, end, _ = self.buckets[b]
         buf = self.arena.grad[start:end]

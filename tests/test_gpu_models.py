@@ -386,3 +386,41 @@ def test_train_step_bf16_runs_and_tracks_fp32(dev):
     for k in ("loss/d", "loss/g"):
         a, b = float(lbf[k]), float(l32[k])
         assert math.isfinite(a) and abs(a - b) <= 3e-2 * max(1.0, abs(b)), (k, a, b)
+
+
+def test_bucket_allreduce_on_rccl_single_rank(dev, monkeypatch):
+    """The data-parallel gradient path on the real backend: a 1-rank RCCL group with the bucket all-reduces
+    forced on (GAN_AMD_FORCE_ALLREDUCE) must reproduce the plain single-process iteration exactly -- the
+    async all-reduces of arena slices fired from the post-accumulate hooks, and their hand-over to the
+    optimizer's stream, are the same code the N-GPU runs use (multi-rank arithmetic: gloo test on CPU)."""
+    import torch.distributed as dist
+    from gan_amd.train_celeba import TrainConfig, Trainer
+
+    def run(force):
+        if force:
+            monkeypatch.setenv("GAN_AMD_FORCE_ALLREDUCE", "1")
+        else:
+            monkeypatch.delenv("GAN_AMD_FORCE_ALLREDUCE", raising=False)
+        torch.manual_seed(7)
+        cfg = TrainConfig(model="stylegan2", img_size=32, gen_kwargs={"base_dim": 64}, disc_kwargs={"base_dim": 16},
+                          method="hinge", regularizer="r1", batch_size=8, optimizer="Adam", optimizer_kwargs={"betas": [0, 0.9]},
+                          lr=2e-4, device="cuda", mixed_precision=False, channels_last=False)
+        tr = Trainer(cfg, dev)
+        reals = torch.randn(8, 3, 32, 32, device=dev)
+        out = []
+        for _ in range(3):
+            logs = tr.train_step(lambda: reals.clone())
+            out.append((float(logs["loss/d"]), float(logs["loss/g"])))
+        return out, [r._fired for r in (tr.red_d, tr.red_g)]
+
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+    monkeypatch.setenv("MASTER_PORT", "29731")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        forced, fired = run(True)
+        plain, _ = run(False)
+    finally:
+        dist.destroy_process_group()
+    assert all(all(f) for f in fired)
+    for a, b in zip(forced, plain):
+        assert abs(a[0] - b[0]) <= 1e-3 * max(1.0, abs(b[0])) and abs(a[1] - b[1]) <= 1e-3 * max(1.0, abs(b[1])), (forced, plain)
