@@ -53,7 +53,7 @@ def parse():
     ap.add_argument("--no_cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no_micro", action="store_true", help="skip the upfirdn2d microbenchmark leg")
     ap.add_argument("--no_roofline", action="store_true")
-    ap.add_argument("--graph", action="store_true", help="replay the iteration as one HIP graph instead of launching every kernel from the host (N=1; measured +0.7 %)")
+    ap.add_argument("--no_graph", action="store_true", help="launch every kernel from the host instead of replaying the iteration as HIP graphs")
     ap.add_argument("--micro_only", action="store_true", help="run only the upfirdn2d microbenchmark leg and print it")
     return ap.parse_args()
 
@@ -69,7 +69,7 @@ def make_trainer(args, device, world):
         model="stylegan2", img_size=args.img_size, gen_kwargs={"base_dim": args.base_dim}, disc_kwargs={"base_dim": args.base_dim},
         method="hinge", regularizer="r1", batch_size=args.global_batch, optimizer="Adam", optimizer_kwargs={"betas": [0.0, 0.9]},
         lr=2e-4, device="cuda", mixed_precision=not args.fp32, channels_last=True, grad_accum=accum,
-        hip_graph=(world == 1 and args.graph), graph_warmup=1,
+        hip_graph=not args.no_graph, graph_warmup=1,
     )
     return cfg, Trainer(cfg, device, world), local // accum
 
@@ -83,7 +83,7 @@ def roofline_leg(trainer, next_reals):
     GF.set_profile(prof)
     try:
         GF._PACK_CACHE.clear()
-        trainer._iteration(next_reals)  # launched from the host even when the timed steps replay a HIP graph
+        trainer._run_eager(next_reals)  # launched from the host even when the timed steps replay HIP graphs
         torch.cuda.synchronize()
     finally:
         GF.set_profile(None)

@@ -109,42 +109,89 @@ class Trainer:
         """One generator iteration = the `while` body of train_celeba.py:111-149.  `next_reals()` returns
         this rank's (local_batch // grad_accum, 3, S, S) real images, already on the device.
 
-        With cfg.hip_graph (single process only) the whole iteration except the EMA update -- both forward /
-        backward passes, R1, both optimizer steps: ~2600 kernel launches -- is captured once into a HIP graph
-        after `graph_warmup` eager iterations and replayed from then on: the launches cost no host time and
-        the GPU no idle gaps between them.  The EMA weight follows a host-side schedule (utils.py:85-96), so
-        that one launch stays outside the graph."""
-        if self.cfg.hip_graph and self.world == 1:
+        With cfg.hip_graph the iteration is captured once, after `graph_warmup` eager iterations, into HIP
+        graphs and replayed from then on: its ~2600 kernel launches cost no host time, which is what bounds
+        the step at small per-GPU batches (30 ms at batch 32 launched from Python).  The graphs are cut where
+        the gradients are averaged across ranks -- those all-reduces (one flat arena each) and the EMA update,
+        whose weight follows a host-side schedule (utils.py:85-96), stay ordinary launches between replays."""
+        if self.cfg.hip_graph:
             logs = self._graph_step(next_reals)
         else:
-            logs = self._iteration(next_reals)
+            logs = self._run_eager(next_reals)
         self.gen_ema.step()
         self.step += 1
         return logs
 
+    # ---- eager: gradient buckets are all-reduced from hooks while the backward pass is still running ----
+    def _run_eager(self, next_reals: Callable[[], Tensor]) -> Dict[str, Tensor]:
+        it = self._iteration(next_reals, overlap=True)
+        try:
+            while True:
+                next(it)
+        except StopIteration as stop:
+            return stop.value
+
+    def _flat_allreduce(self, red: GradBucketReducer) -> None:
+        if red.world > 1 or red._force:
+            import torch.distributed as dist
+
+            red.arena.grad.div_(red.world)
+            dist.all_reduce(red.arena.grad, op=dist.ReduceOp.SUM, group=red.group)
+
+    # ---- HIP graphs ---------------------------------------------------------------------------------
     def _graph_step(self, next_reals: Callable[[], Tensor]) -> Dict[str, Tensor]:
         cfg = self.cfg
         if self._graph is None:
             if self.step < cfg.graph_warmup:
-                return self._iteration(next_reals)
+                return self._run_eager(next_reals)
             n_fetch = cfg.n_disc * cfg.grad_accum
             self._graph_reals = [next_reals().clone() for _ in range(n_fetch)]
-            GF._PACK_CACHE.clear()  # every packed weight the graph reads must be packed inside it
+            GF._PACK_CACHE.clear()  # every packed weight the graphs read must be packed inside them
             feed = iter(self._graph_reals)
-            graph = torch.cuda.CUDAGraph()
+            # `.detach()`: an alias, so that requires_grad_ stays off the static buffer
+            it = self._iteration(lambda: next(feed).detach(), overlap=False)
+            segments = []  # (graph, reducer whose arena is averaged after it | None)
+            pool = torch.cuda.graph_pool_handle()
             torch.cuda.synchronize()
-            with torch.cuda.graph(graph):
-                self._graph_logs = self._iteration(lambda: next(feed).detach())  # an alias: requires_grad_ stays off the buffer
-            self._graph = graph
-            # the capture pass does not execute: run the iteration it recorded on the data it fetched
+            done = False
+            try:
+                while not done:
+                    graph = torch.cuda.CUDAGraph()
+                    red = None
+                    with torch.cuda.graph(graph, pool=pool):
+                        try:
+                            red = next(it)
+                        except StopIteration as stop:
+                            self._graph_logs = stop.value
+                            done = True
+                    segments.append((graph, red))
+            except Exception as exc:  # capture refused (driver / allocator state): keep training, launched from the host
+                import sys
+
+                print(f"gan_amd: HIP graph capture failed ({type(exc).__name__}: {exc}); continuing without graphs", file=sys.stderr)
+                it.close()
+                self.cfg.hip_graph = False
+                self.disc.requires_grad_(True)
+                self.red_d.zero_grad()
+                self.red_g.zero_grad()
+                torch.cuda.synchronize()
+                return self._run_eager(lambda: self._graph_reals[0])
+            self._graph = segments
+            # capture does not execute: the replay below runs the iteration on the data just fetched
         else:
             for buf in self._graph_reals:
                 buf.copy_(next_reals())
-        self._graph.replay()
+        for graph, red in self._graph:
+            graph.replay()
+            if red is not None:
+                self._flat_allreduce(red)
         GF._PACK_CACHE.clear()  # a replay updates the weights without bumping their Python-side versions
         return {k: v.clone() for k, v in self._graph_logs.items()}
 
-    def _iteration(self, next_reals: Callable[[], Tensor]) -> Dict[str, Tensor]:
+    def _iteration(self, next_reals: Callable[[], Tensor], overlap: bool):
+        """The iteration as a generator: with overlap=False it yields the reducer whose gradient arena must be
+        averaged across ranks at that point (the cuts between the HIP graphs); with overlap=True the buckets
+        are reduced from hooks during the backward pass and nothing is yielded.  Returns the log dict."""
         cfg, disc, gen = self.cfg, self.disc, self.gen
         for i in range(cfg.n_disc):
             cached_reals: Optional[List[Tensor]] = [] if i == cfg.n_disc - 1 else None
@@ -167,28 +214,35 @@ class Trainer:
                     if self.regularizer is not None:
                         loss_d = loss_d + self.regularizer(disc, reals, fakes, d_reals)
                 last = a == cfg.grad_accum - 1
-                if last:
+                if last and overlap:
                     self.red_d.prepare()
                 loss_d.backward()
                 if last:
-                    self.red_d.finish()
+                    if overlap:
+                        self.red_d.finish()
+                    else:
+                        yield self.red_d
             self.optim_d.step()
             self.red_d.zero_grad()
 
         disc.requires_grad_(False)
-        for a in range(cfg.grad_accum):
-            zs = torch.randn(reals.shape[0], self.z_dim, device=self.device)
-            with self.autocast_ctx():
-                loss_g = self.criterion.g_loss(disc(gen(zs)), lambda: disc(cached_reals[a]))
-            last = a == cfg.grad_accum - 1
-            if last:
-                self.red_g.prepare()
-            loss_g.backward()
-            if last:
-                self.red_g.finish()
+        try:
+            for a in range(cfg.grad_accum):
+                zs = torch.randn(reals.shape[0], self.z_dim, device=self.device)
+                with self.autocast_ctx():
+                    loss_g = self.criterion.g_loss(disc(gen(zs)), lambda: disc(cached_reals[a]))
+                last = a == cfg.grad_accum - 1
+                if last and overlap:
+                    self.red_g.prepare()
+                loss_g.backward()
+                if last and overlap:
+                    self.red_g.finish()
+        finally:
+            disc.requires_grad_(True)
+        if not overlap:
+            yield self.red_g
         self.optim_g.step()
         self.red_g.zero_grad()
-        disc.requires_grad_(True)
         # tensors, not floats: no host sync here (the reference syncs every 50 steps, train_celeba.py:153-160)
         return {"loss/d": loss_d.detach(), "d/real": d_reals.detach().mean(), "d/fake": d_fakes.detach().mean(), "loss/g": loss_g.detach()}
 

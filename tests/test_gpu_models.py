@@ -424,3 +424,53 @@ def test_bucket_allreduce_on_rccl_single_rank(dev, monkeypatch):
     assert all(all(f) for f in fired)
     for a, b in zip(forced, plain):
         assert abs(a[0] - b[0]) <= 1e-3 * max(1.0, abs(b[0])) and abs(a[1] - b[1]) <= 1e-3 * max(1.0, abs(b[1])), (forced, plain)
+
+
+def test_hip_graph_iteration_matches_eager(dev, monkeypatch):
+    """cfg.hip_graph: the iteration replayed as HIP graphs (cut at the gradient all-reduces, which run between
+    the replays on a 1-rank RCCL group here) against the same iteration launched from the host.  torch.randn
+    is pinned to fixed draws so both see the same latents and noise."""
+    import torch.distributed as dist
+    from gan_amd.train_celeba import TrainConfig, Trainer
+
+    real_randn = torch.randn
+    cache = {}
+
+    def fixed_randn(*shape, **kw):
+        shape = tuple(shape[0]) if len(shape) == 1 and isinstance(shape[0], (tuple, list, torch.Size)) else tuple(shape)
+        key = (shape, str(kw.get("dtype")), str(kw.get("device")))
+        if key not in cache:
+            g = torch.Generator(device="cpu").manual_seed(len(cache) + 11)
+            cache[key] = real_randn(*shape, generator=g).to(device=kw.get("device"), dtype=kw.get("dtype") or torch.float32)
+        return cache[key]
+
+    def run(graph):
+        torch.manual_seed(7)
+        cfg = TrainConfig(model="stylegan2", img_size=32, gen_kwargs={"base_dim": 64}, disc_kwargs={"base_dim": 16},
+                          method="hinge", regularizer="r1", batch_size=8, optimizer="Adam", optimizer_kwargs={"betas": [0, 0.9]},
+                          lr=2e-4, device="cuda", mixed_precision=False, channels_last=False, hip_graph=graph, graph_warmup=1)
+        tr = Trainer(cfg, dev)
+        g = torch.Generator(device="cpu").manual_seed(3)
+        pool = [real_randn(8, 3, 32, 32, generator=g).to(dev) for _ in range(5)]
+        out = []
+        monkeypatch.setattr(torch, "randn", fixed_randn)
+        try:
+            for i in range(4):  # the iteration is chaotic: a 1e-7 reduction-order difference is ~2e-2 by the 5th step
+                logs = tr.train_step(lambda: pool[i])
+                out.append((float(logs["loss/d"]), float(logs["loss/g"])))
+        finally:
+            monkeypatch.setattr(torch, "randn", real_randn)
+        return out, tr
+
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+    monkeypatch.setenv("MASTER_PORT", "29733")
+    monkeypatch.setenv("GAN_AMD_FORCE_ALLREDUCE", "1")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        eager, _ = run(False)
+        graphed, tr = run(True)
+    finally:
+        dist.destroy_process_group()
+    assert tr._graph is not None and len(tr._graph) == 3  # D pass | D update + G pass | G update
+    for i, (a, b) in enumerate(zip(graphed, eager)):
+        assert abs(a[0] - b[0]) <= 1e-2 * max(1.0, abs(b[0])) and abs(a[1] - b[1]) <= 1e-2 * max(1.0, abs(b[1])), (i, graphed, eager)
