@@ -282,11 +282,25 @@ def raw_scale_dot(A: Tensor, B: Tensor, a: Tensor):
     return out, dot
 
 
+# The last channel-padded copy of a tensor (RGB 3 -> 16 is a 0.5 GB pass at 256x256, batch 256): the
+# forward convolution and the weight gradient of the same layer pad the same input.
+_PAD_MEMO: dict = {}
+
+
 def _pad_channels(x: Tensor, mult: int) -> Tensor:
     c = x.shape[1]
     rem = (-c) % mult
     if rem == 0:
         return as_cl(x)
+    if c < 8:  # image-like input: pad once to 16 for both users (conv forward wants 8, weight gradient 16)
+        rem = 16 - c
+        key = (x.data_ptr(), x._version, tuple(x.shape), tuple(x.stride()), x.dtype)
+        hit = _PAD_MEMO.get("last")
+        if hit is not None and hit[0] == key:
+            return hit[2]
+        out = as_cl(F.pad(x, (0, 0, 0, 0, 0, rem)))
+        _PAD_MEMO["last"] = (key, x, out)  # x is held: its storage cannot be recycled under the same key
+        return out
     return as_cl(F.pad(x, (0, 0, 0, 0, 0, rem)))
 
 
@@ -379,7 +393,7 @@ def raw_conv2d(
     cout, cin, kh, kw = weight.shape
     if transposed:
         cout, cin = cin, cout
-    wt, cin_p2, kpad = pack_weight(weight, x.dtype, transposed=transposed)
+    wt, cin_p2, kpad = pack_weight(weight, x.dtype, cin_mult=16 if cin < 8 else 8, transposed=transposed)
     if cin_p2 != cin_p:
         raise _lib.GanAmdError(f"conv2d: input has {x.shape[1]} (padded) channels, weight expects {cin}")
     hl, wl = (2 * h, 2 * w) if up2 else (h, w)
@@ -546,7 +560,8 @@ class UpFirDnFn(Function):
             a1x, a1y = kx - 1 - px1, ky - 1 - py1
             a2x = (w - 1) * up + kx - wo * down - a1x
             a2y = (h - 1) * up + ky - ho * down - a1y
-            gx = UpFirDnFn.apply(gy, taps.flip(0, 1), down, up, a1x, a2x, a1y, a2y, h, w)
+            flipped = taps if taps.numel() == 4 and taps.data_ptr() in _CONST_TAPS else taps.flip(0, 1)  # constant taps are symmetric
+            gx = UpFirDnFn.apply(gy, flipped, down, up, a1x, a2x, a1y, a2y, h, w)
         return (gx,) + (None,) * 9
 
 
@@ -758,8 +773,19 @@ def upfirdn2d(imgs: Tensor, kernel: Tensor, up: int, down: int, px1: int, px2: i
     return UpFirDnFn.apply(imgs, kernel, up, down, px1, px2, py1, py2)
 
 
+_TAPS: dict = {}
+_CONST_TAPS: set = set()
+
+
 def _ones_taps(x: Tensor, value: float) -> Tensor:
-    return torch.full((2, 2), value, dtype=torch.float32, device=x.device)
+    """Constant 2x2 taps, one tensor per (device, value) for the life of the process (they were a fill
+    launch per nearest-up / avg-pool call)."""
+    key = (x.device, value)
+    t = _TAPS.get(key)
+    if t is None:
+        t = _TAPS[key] = torch.full((2, 2), value, dtype=torch.float32, device=x.device)
+        _CONST_TAPS.add(t.data_ptr())
+    return t
 
 
 def nearest_up2(x: Tensor) -> Tensor:

@@ -126,7 +126,7 @@ class ModConvFn(Function):
             if need[0]:
                 gx = GF.ChanScaleFn.apply(gxs, s)
                 if up2:  # adjoint of nearest x2: sum of each 2x2 block
-                    gx = GF.UpFirDnFn.apply(gx, torch.ones(2, 2, device=gx.device), 1, 2, 0, 0, 0, 0)
+                    gx = GF.UpFirDnFn.apply(gx, GF._ones_taps(gx, 1.0), 1, 2, 0, 0, 0, 0)
         if need[1]:
             gw = GF.Conv2dWgradFn.apply(xs, gz, kh, kw, pad, pad).to(weight.dtype)
         return gx, gw, gs, gdinv, gb, None, gns, None, None

@@ -147,6 +147,7 @@ class Trainer:
             n_fetch = cfg.n_disc * cfg.grad_accum
             self._graph_reals = [next_reals().clone() for _ in range(n_fetch)]
             GF._PACK_CACHE.clear()  # every packed weight the graphs read must be packed inside them
+            GF._PAD_MEMO.clear()
             feed = iter(self._graph_reals)
             # `.detach()`: an alias, so that requires_grad_ stays off the static buffer
             it = self._iteration(lambda: next(feed).detach(), overlap=False)
@@ -186,6 +187,7 @@ class Trainer:
             if red is not None:
                 self._flat_allreduce(red)
         GF._PACK_CACHE.clear()  # a replay updates the weights without bumping their Python-side versions
+        GF._PAD_MEMO.clear()
         return {k: v.clone() for k, v in self._graph_logs.items()}
 
     def _iteration(self, next_reals: Callable[[], Tensor], overlap: bool):
@@ -202,7 +204,7 @@ class Trainer:
             for a in range(cfg.grad_accum):
                 reals = next_reals()
                 if cached_reals is not None:
-                    cached_reals.append(reals.clone())
+                    cached_reals.append(reals.detach())  # an alias (only the relativistic loss reads it back)
                 reals.requires_grad_()
                 zs = torch.randn(reals.shape[0], self.z_dim, device=self.device)
                 with self.autocast_ctx():

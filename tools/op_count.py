@@ -2,7 +2,7 @@
 (profiling aid): python tools/op_count.py"""
 import sys, collections, torch
 sys.path.insert(0, '.')
-sys.argv = ['bench.py']
+sys.argv = ['bench.py', '--no_graph']
 import bench
 from gan_amd.train_celeba import synthetic_reals
 from torch.profiler import profile, ProfilerActivity
@@ -14,7 +14,7 @@ nxt = synthetic_reals(cfg, dev, micro, seed=0)
 for _ in range(2):
     tr.train_step(nxt)
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=False, record_shapes=True) as prof:
     tr.train_step(nxt)
     torch.cuda.synchronize()
 by_src = collections.Counter()
@@ -25,11 +25,10 @@ for ev in prof.events():
     kt = sum(k.duration for k in ev.kernels)
     if not ev.kernels:
         continue
-    src = next((f for f in ev.stack if '/root/repo/' in f or 'gan_amd' in f), ev.stack[0] if ev.stack else '?')
-    key = (ev.name, src.split('/')[-1][:70])
+    key = (ev.name, str(ev.input_shapes)[:90])
     by_src[key] += len(ev.kernels)
     dur[key] += kt
-rows = sorted(by_src, key=lambda k: -dur[k])[:70]
+rows = sorted(by_src, key=lambda k: -dur[k])[:90]
 for k in rows:
     print(f"{by_src[k]:5d} {dur[k]/1e3:8.3f} ms  {k[0]:28s} {k[1]}")
 print('total kernels from aten ops', sum(by_src.values()), 'ms', sum(dur.values()) / 1e3)
