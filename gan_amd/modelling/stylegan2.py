@@ -248,7 +248,8 @@ class StyleGan2Generator(nn.Module):
 
     def forward(self, z: Tensor) -> Tensor:
         # mapping network: 8 x (128x128 Linear + LeakyReLU) on (N,128) -- plain library GEMMs (hipBLASLt)
-        w = self.mapping_network(z)
+        with torch.autocast("cuda", enabled=False):  # (N,128) x (128,128) products: fp32 costs nothing and spares
+            w = self.mapping_network(z.float())       # a bf16 cast of every weight and bias per call
         self._all_styles(w)
         dt = GF.act_dtype(z)
         x = self.learned_input.to(dt).expand(z.shape[0], -1, -1, -1)

@@ -218,14 +218,18 @@ class Trainer:
                 last = a == cfg.grad_accum - 1
                 if last and overlap:
                     self.red_d.prepare()
+                if a == 0 and not overlap:
+                    self.red_d.arena.detach_grads()
                 loss_d.backward()
                 if last:
                     if overlap:
                         self.red_d.finish()
                     else:
+                        self.red_d.arena.gather_grads()
                         yield self.red_d
             self.optim_d.step()
-            self.red_d.zero_grad()
+            if overlap:
+                self.red_d.zero_grad()
 
         disc.requires_grad_(False)
         try:
@@ -236,15 +240,19 @@ class Trainer:
                 last = a == cfg.grad_accum - 1
                 if last and overlap:
                     self.red_g.prepare()
+                if a == 0 and not overlap:
+                    self.red_g.arena.detach_grads()
                 loss_g.backward()
                 if last and overlap:
                     self.red_g.finish()
         finally:
             disc.requires_grad_(True)
         if not overlap:
+            self.red_g.arena.gather_grads()
             yield self.red_g
         self.optim_g.step()
-        self.red_g.zero_grad()
+        if overlap:
+            self.red_g.zero_grad()
         # tensors, not floats: no host sync here (the reference syncs every 50 steps, train_celeba.py:153-160)
         return {"loss/d": loss_d.detach(), "d/real": d_reals.detach().mean(), "d/fake": d_fakes.detach().mean(), "loss/g": loss_g.detach()}
 

@@ -121,6 +121,28 @@ class FlatArena:
         for p, o in zip(self.params, self.offsets):
             p.grad = self.grad[o : o + p.numel()].view(p.shape)
 
+    def detach_grads(self) -> None:
+        """p.grad = None: the next backward pass hands its gradient tensors over instead of adding them into
+        the arena slices one launch per parameter; gather_grads() then files them with one multi-tensor copy."""
+        for p in self.params:
+            p.grad = None
+
+    def gather_grads(self) -> None:
+        views, srcs, missing = [], [], False
+        for p, o in zip(self.params, self.offsets):
+            g = p.grad
+            if g is None:
+                missing = missing or p.requires_grad
+                continue
+            if g.data_ptr() != self.grad.data_ptr() + 4 * o:
+                views.append(self.grad[o : o + p.numel()].view(p.shape))
+                srcs.append(g)
+        if missing:
+            self.grad.zero_()  # a parameter that took no part in this pass: its slice must read zero
+        if views:
+            torch._foreach_copy_(views, srcs)
+        self.attach_grads()
+
     def intact(self) -> bool:
         """False once someone replaced p.data (model.to(...), .half(), load with assign=True)."""
         base = self.data.data_ptr()
