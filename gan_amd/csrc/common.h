@@ -124,13 +124,14 @@ __device__ __forceinline__ uint4 lrelu_chunk(uint4 raw, float slope, float) {
 
 // The fused stages around a convolution beyond modulation / bias / noise / activation (include/gan_amd.h):
 // leaky-ReLU of the input as it is staged, 2x2 average pooling of the result, a final multiply by the
-// leaky-ReLU derivative mask of `aux` (a tensor shaped like the output), and a scalar gain.
+// leaky-ReLU derivative mask of `aux` (a tensor shaped like the output), a scalar gain, a final residual add.
 struct ConvFuse {
     float in_slope;   // 1 = no input activation
     int pool;         // 1 = 2x2 average pooling; bias / noise / aux / y are at the pooled resolution
     const void* aux;  // nullptr = no mask
     float aux_slope;
     float gain;
+    const void* resid;  // nullptr, or a tensor shaped like y added to the result last (a second gradient path)
 };
 
 // conv_thin.hip: direct convolution for thin layers (bf16).  1 = served, 0 = shape not eligible, < 0 = error.

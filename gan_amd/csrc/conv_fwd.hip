@@ -283,6 +283,7 @@ __global__ void __launch_bounds__(256) conv_fwd_k(const ConvArgs p) {
     T* __restrict__ y = (T*)p.y;
     const T* __restrict__ noise = (const T*)p.noise;
     const T* __restrict__ aux = (const T*)p.fu.aux;
+    const T* __restrict__ resid = (const T*)p.fu.resid;
     const int nr = p.fu.pool ? 1 : 4;               // pooled: the lane's four rows are one 2x2 window
     const int out_per_img = p.fu.pool ? HoWo >> 2 : HoWo;
 #pragma unroll
@@ -306,6 +307,7 @@ __global__ void __launch_bounds__(256) conv_fwd_k(const ConvArgs p) {
                 if (noise) v = fmaf(nz, p.noise_scale[co], v);
                 v = lrelu_f(v, p.slope);
                 if (aux) v *= lrelu_mask((float)aux[m * p.Cout + co], p.fu.aux_slope);
+                if (resid) v += (float)resid[m * p.Cout + co];
                 y[m * p.Cout + co] = (T)v;
             }
         }
@@ -351,7 +353,7 @@ int launch(const ConvArgs& a, hipStream_t st) {
 extern "C" int gan_conv2d_fwd(const void* x, const void* wt, void* y, const float* in_scale, const float* out_scale,
                               const float* bias, const void* noise, const float* noise_scale, float slope, int N,
                               int H, int W, int Cin, int up2, int Ho, int Wo, int Cout, int kh, int kw, int py, int px,
-                              int Kpad, float in_slope, int pool, const void* aux, float aux_slope, float gain,
+                              int Kpad, float in_slope, int pool, const void* aux, float aux_slope, float gain, const void* resid,
                               int dtype, gan_stream_t stream) {
     GAN_CHECK_ARG(N == 0 || (x && wt && y), "conv2d_fwd: null pointer");
     GAN_CHECK_ARG(dtype == GAN_F32 || dtype == GAN_BF16, "conv2d_fwd: bad dtype %d", dtype);
@@ -370,7 +372,7 @@ extern "C" int gan_conv2d_fwd(const void* x, const void* wt, void* y, const floa
     GAN_CHECK_ARG(pool == 0 || (pool == 1 && Ho % 2 == 0 && Wo % 2 == 0), "conv2d_fwd: pooling needs an even %dx%d output", Ho, Wo);
     if (N == 0) return GAN_OK;
     ConvArgs a;
-    a.fu.in_slope = in_slope; a.fu.pool = pool; a.fu.aux = aux; a.fu.aux_slope = aux_slope; a.fu.gain = gain;
+    a.fu.in_slope = in_slope; a.fu.pool = pool; a.fu.aux = aux; a.fu.aux_slope = aux_slope; a.fu.gain = gain; a.fu.resid = resid;
     a.x = x; a.wt = wt; a.y = y;
     a.in_scale = in_scale; a.out_scale = out_scale; a.bias = bias;
     a.noise = noise; a.noise_scale = noise_scale; a.slope = slope;

@@ -13,9 +13,10 @@ int gan_conv2d_fwd_thin(const void* x, const void* wt, void* y, const float* in_
     if (Kpad != (kh * kw * Cin + 31) / 32 * 32) return 0;
     if (((uintptr_t)y % 8) != 0 || ((uintptr_t)fu.aux % 8) != 0 || ((uintptr_t)in_scale % 16) != 0) return 0;
     const bool g_stage = in_scale || out_scale || noise;
-    const bool d_stage = fu.in_slope != 1.f || fu.pool || fu.aux || fu.gain != 1.f;
+    const bool d_stage = fu.in_slope != 1.f || fu.pool || fu.aux || fu.gain != 1.f || fu.resid;
     if (g_stage && d_stage) return 0;  // no caller mixes them; the implicit-GEMM kernel takes every combination
     if (fu.pool && fu.aux) return 0;
+    if (fu.resid && (!fu.aux || ((uintptr_t)fu.resid % 8) != 0 || (Cout & 3))) return 0;  // the residual rides in the mask mode only
     if ((Cout & 3) && (Cout > 16 || fu.pool)) return 0;  // 2-byte stores: to-/from-RGB widths only
     // 32-bit buffer offsets
     const int64_t xb = (int64_t)N * H * W * Cin * 2;

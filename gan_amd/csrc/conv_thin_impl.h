@@ -31,7 +31,7 @@
 enum ThinMode {
     THIN_G = 0,   // in_scale, out_scale, bias, noise, slope            (ModulatedConv2d, stylegan2.py:29-36)
     THIN_D = 1,   // in_slope, bias, slope, gain                        (LeakyReLU -> Conv2d, progressive_gan.py:45-48)
-    THIN_DA = 2,  // THIN_D + leaky-ReLU mask of `aux` on the result    (input gradients of the above)
+    THIN_DA = 2,  // THIN_D + leaky-ReLU mask of `aux` on the result, + resid  (input gradients of the above)
     THIN_DP = 3,  // THIN_D + 2x2 average pooling of the result         (LeakyReLU -> Conv2d -> AvgPool2d, :48-50)
 };
 
@@ -123,6 +123,7 @@ __global__ void __launch_bounds__(256, 2) conv_thin_k(const ThinArgs p) {
     const __amdgpu_buffer_rsrc_t rx = thin_rsrc(p.x, p.x_bytes);
     const __amdgpu_buffer_rsrc_t ry = thin_rsrc(p.y, p.y_bytes);
     const __amdgpu_buffer_rsrc_t raux = thin_rsrc(AUX ? p.fu.aux : nullptr, p.y_bytes);
+    const __amdgpu_buffer_rsrc_t rres = thin_rsrc(AUX ? p.fu.resid : nullptr, p.y_bytes);
     const __amdgpu_buffer_rsrc_t rnoise = thin_rsrc(G ? p.noise : nullptr, p.Cout ? p.y_bytes / (unsigned)p.Cout : 0u);
     const __amdgpu_buffer_rsrc_t rosc = thin_rsrc(G ? p.out_scale : nullptr, (unsigned)(p.N * p.Cout) * 4u);
     const __amdgpu_buffer_rsrc_t rsty = thin_rsrc(G ? p.in_scale : nullptr, (unsigned)(p.N * CIN) * 4u);
@@ -243,7 +244,7 @@ __global__ void __launch_bounds__(256, 2) conv_thin_k(const ThinArgs p) {
 #pragma unroll
         for (int e0 = 0; e0 < NE; e0 += EB) {
             float nz[EB];
-            v2u ax[EB][FCO];
+            v2u ax[EB][FCO], rs[EB][FCO];
             unsigned mo[EB];  // byte offset of the pixel's channel 0 in y (and aux), THIN_INV for a dead slot
 #pragma unroll
             for (int k = 0; k < EB; ++k) {
@@ -272,6 +273,7 @@ __global__ void __launch_bounds__(256, 2) conv_thin_k(const ThinArgs p) {
                     for (int i = 0; i < FCO; ++i) {
                         const int co0 = i * 16 + kg * 4;
                         ax[k][i] = __builtin_amdgcn_raw_buffer_load_b64(raux, (live && co0 < p.Cout) ? mo[k] + co0 * 2 : THIN_INV, 0, 0);
+                        rs[k][i] = __builtin_amdgcn_raw_buffer_load_b64(rres, (live && co0 < p.Cout) ? mo[k] + co0 * 2 : THIN_INV, 0, 0);
                     }
                 }
             }
@@ -308,9 +310,9 @@ __global__ void __launch_bounds__(256, 2) conv_thin_k(const ThinArgs p) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] = lrelu_f(v[j], p.slope);
                     if (AUX) {
-                        const bf16x4 a4 = __builtin_bit_cast(bf16x4, ax[k][i]);
+                        const bf16x4 a4 = __builtin_bit_cast(bf16x4, ax[k][i]), r4 = __builtin_bit_cast(bf16x4, rs[k][i]);
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] *= lrelu_mask((float)a4[j], p.fu.aux_slope);
+                        for (int j = 0; j < 4; ++j) v[j] = fmaf(v[j], lrelu_mask((float)a4[j], p.fu.aux_slope), (float)r4[j]);  // resid: zeros if absent
                     }
                     bf16x4 o;
 #pragma unroll

@@ -37,6 +37,7 @@ struct WideArgs {
     const void* noise;
     const float* noise_scale;
     const void* aux;
+    const void* resid;
     float slope, aux_slope, gain;
     int N, H, W, Cin, Hl, Wl, up2, Ho, Wo, Cout, kw, py, px, Kpad, ksteps, pool;
     int M;
@@ -189,6 +190,7 @@ __global__ void __launch_bounds__(256, 2) conv_wide_k(const WideArgs p) {
     // ---- epilogue: lane holds channels co0..co0+3 (co0 = bn0 + wn*BN/2 + 16*i + 4*fq) of pixel row f*16 + frow
     const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t raux = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.aux), 0, p.aux ? p.y_bytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.resid), 0, p.resid ? p.y_bytes : 0u, 0x00020000);
     const __amdgpu_buffer_rsrc_t rnz =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.noise), 0, p.noise ? p.y_bytes / (unsigned)p.Cout : 0u, 0x00020000);
     const __amdgpu_buffer_rsrc_t rosc =
@@ -214,12 +216,13 @@ __global__ void __launch_bounds__(256, 2) conv_wide_k(const WideArgs p) {
         // every per-pixel load of this fragment row first, then its stores
         float nz = 0.f;
         if (p.noise) nz = (float)__builtin_bit_cast(bf16, __builtin_amdgcn_raw_buffer_load_b16(rnz, live ? (unsigned)opix * 2u : WIDE_INV, 0, 0));
-        v2u ax[FC];
+        v2u ax[FC], rs[FC];
         v4u os[FC];
 #pragma unroll
         for (int i = 0; i < FC; ++i) {
             const bool cok = live && co0[i] < p.Cout;
             ax[i] = __builtin_amdgcn_raw_buffer_load_b64(raux, cok ? obase + co0[i] * 2 : WIDE_INV, 0, 0);
+            rs[i] = __builtin_amdgcn_raw_buffer_load_b64(rres, cok ? obase + co0[i] * 2 : WIDE_INV, 0, 0);
             os[i] = __builtin_amdgcn_raw_buffer_load_b128(rosc, cok ? (unsigned)(n * p.Cout + co0[i]) * 4u : WIDE_INV, 0, 0);
         }
 #pragma unroll
@@ -240,11 +243,12 @@ __global__ void __launch_bounds__(256, 2) conv_wide_k(const WideArgs p) {
             v[2] = fmaf(nz, nsc[i].z, fmaf(v[2], d4.z, bia[i].z));
             v[3] = fmaf(nz, nsc[i].w, fmaf(v[3], d4.w, bia[i].w));
             bf16x4 o;
-            const bf16x4 a4 = __builtin_bit_cast(bf16x4, ax[i]);
+            const bf16x4 a4 = __builtin_bit_cast(bf16x4, ax[i]), r4 = __builtin_bit_cast(bf16x4, rs[i]);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float u = lrelu_f(v[r], p.slope);
                 if (p.aux) u *= lrelu_mask((float)a4[r], p.aux_slope);
+                u += (float)r4[r];  // zeros without a residual (out-of-range load)
                 o[r] = (bf16)u;
             }
             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, o), ry, (live && co0[i] < p.Cout) ? obase + co0[i] * 2 : WIDE_INV, 0, 0);
@@ -264,13 +268,13 @@ int gan_conv2d_fwd_wide(const void* x, const void* wt, void* y, const float* out
     const int64_t xb = (int64_t)N * H * W * Cin * 2, wb = (int64_t)Cout * Kpad * 2;
     const int64_t yb = (fu.pool ? M / 4 : M) * Cout * 2;
     if (M < 128 || M >= (1LL << 31) - 256 || xb >= (1LL << 31) || wb >= (1LL << 31) || yb >= (1LL << 31)) return 0;
-    if (((uintptr_t)y & 7) || ((uintptr_t)fu.aux & 7) || ((uintptr_t)out_scale & 15) || ((uintptr_t)bias & 15) ||
+    if (((uintptr_t)y & 7) || ((uintptr_t)fu.aux & 7) || ((uintptr_t)fu.resid & 7) || ((uintptr_t)out_scale & 15) || ((uintptr_t)bias & 15) ||
         ((uintptr_t)noise_scale & 15))
         return 0;
     if (H >= 32768 || W >= 32768) return 0;
     WideArgs a;
     a.x = x; a.wt = wt; a.y = y; a.out_scale = out_scale; a.bias = bias; a.noise = noise; a.noise_scale = noise_scale;
-    a.aux = fu.aux; a.slope = slope; a.aux_slope = fu.aux_slope; a.gain = fu.gain;
+    a.aux = fu.aux; a.resid = fu.resid; a.slope = slope; a.aux_slope = fu.aux_slope; a.gain = fu.gain;
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Hl = up2 ? 2 * H : H; a.Wl = up2 ? 2 * W : W; a.up2 = up2;
     a.Ho = Ho; a.Wo = Wo; a.Cout = Cout; a.kw = kw; a.py = py; a.px = px; a.Kpad = Kpad; a.ksteps = Kpad / 64;
     a.pool = fu.pool; a.M = (int)M;

@@ -381,6 +381,7 @@ def raw_conv2d(
     aux: Optional[Tensor] = None,
     aux_slope: float = 1.0,
     gain: float = 1.0,
+    resid: Optional[Tensor] = None,
 ) -> Tensor:
     """Stride-1 correlation of channels-last x with weight (Cout, Cin, kh, kw) + fused prologue/epilogue.
     `transposed`: correlate with the flipped, channel-swapped weights instead (weight is (Cin, Cout, kh, kw)).
@@ -427,6 +428,10 @@ def raw_conv2d(
         if tuple(aux.shape) != (n, cout, hy, wy):
             raise _lib.GanAmdError(f"conv2d: aux shape {tuple(aux.shape)} != output shape {(n, cout, hy, wy)}")
         aux = as_cl(aux.detach().to(x.dtype))
+    if resid is not None:
+        if tuple(resid.shape) != (n, cout, hy, wy):
+            raise _lib.GanAmdError(f"conv2d: resid shape {tuple(resid.shape)} != output shape {(n, cout, hy, wy)}")
+        resid = as_cl(resid.detach().to(x.dtype))
     y = _empty_like_cl(x, (n, cout, hy, wy))
     if _thin_kernel_shape(x, cin_p, cout, ho, wo, kh, kw, py, px):
         # HBM-bound; one family per device kernel instantiation conv_thin_k<CIN, COUT, KS, RPW, MODE, VEC>
@@ -438,11 +443,11 @@ def raw_conv2d(
         family = "conv2d_fwd"
     check(
         _run(
-            family, 2.0 * n * ho * wo * cout * cin * kh * kw, _nbytes(x, y, wt, noise, aux),
+            family, 2.0 * n * ho * wo * cout * cin * kh * kw, _nbytes(x, y, wt, noise, aux, resid),
             lambda: lib.gan_conv2d_fwd(
                 ptr(x), ptr(wt), ptr(y), ptr(in_scale), ptr(out_scale32), ptr(bias32), ptr(noise), ptr(ns32), float(slope),
                 n, h, w, cin_p, int(up2), ho, wo, cout, kh, kw, py, px, kpad,
-                float(in_slope), int(pool), ptr(aux), float(aux_slope), float(gain), dtype_code(x), stream_of(x),
+                float(in_slope), int(pool), ptr(aux), float(aux_slope), float(gain), ptr(resid), dtype_code(x), stream_of(x),
             ),
             (n, cin, ho, wo, cout, kh, int(up2), int(pool)),
         ),
@@ -453,7 +458,7 @@ def raw_conv2d(
 
 def raw_conv2d_dgrad(
     gy: Tensor, weight: Tensor, py: int, px: int, *, out_scale: Optional[Tensor] = None,
-    pooled: bool = False, aux: Optional[Tensor] = None, aux_slope: float = 1.0,
+    pooled: bool = False, aux: Optional[Tensor] = None, aux_slope: float = 1.0, resid: Optional[Tensor] = None,
 ) -> Tensor:
     """Input gradient of a stride-1 correlation = correlation of gy with the transposed, flipped
     weights and padding k-1-p.  Output spatial size is the forward input size.
@@ -461,7 +466,7 @@ def raw_conv2d_dgrad(
     aux: multiply by the leaky-ReLU mask of aux (the activation that preceded the convolution)."""
     cout, cin, kh, kw = weight.shape
     return raw_conv2d(gy, weight, kh - 1 - py, kw - 1 - px, out_scale=out_scale, transposed=True,
-                      up2=pooled, gain=0.25 if pooled else 1.0, aux=aux, aux_slope=aux_slope)
+                      up2=pooled, gain=0.25 if pooled else 1.0, aux=aux, aux_slope=aux_slope, resid=resid)
 
 
 def raw_conv2d_wgrad(
@@ -696,14 +701,15 @@ class Conv2dFn(Function):
 
 
 class Conv2dDgradFn(Function):
-    """gx = m(xaux) * dgrad( PoolAdj?(gy), W ): the adjoint of Conv2dFn in x.  PoolAdj (nearest-2x gather,
-    gain 1/4) and the mask of the activation that preceded the convolution are fused into the kernel."""
+    """gx = m(xaux) * dgrad( PoolAdj?(gy), W ) [+ resid]: the adjoint of Conv2dFn in x.  PoolAdj (nearest-2x
+    gather, gain 1/4), the mask of the activation that preceded the convolution and the gradient arriving at
+    the same tensor along another path (`resid`) are fused into the kernel."""
 
     @staticmethod
-    def forward(ctx, gy, weight, py, px, xaux=None, slope=1.0, pool=False):
+    def forward(ctx, gy, weight, py, px, xaux=None, slope=1.0, pool=False, resid=None):
         ctx.save_for_backward(gy, weight, xaux)
         ctx.cfg = (py, px, slope, pool)
-        return raw_conv2d_dgrad(gy, weight, py, px, pooled=pool, aux=xaux, aux_slope=slope)
+        return raw_conv2d_dgrad(gy, weight, py, px, pooled=pool, aux=xaux, aux_slope=slope, resid=resid)
 
     @staticmethod
     def backward(ctx, ggx):
@@ -714,7 +720,52 @@ class Conv2dDgradFn(Function):
         g_w = None
         if _need(ctx, 1):
             g_w = Conv2dWgradFn.apply(z, gy, weight.shape[2], weight.shape[3], py, px, 1.0, pool).to(weight.dtype)
-        return g_gy, g_w, None, None, None, None, None
+        g_resid = ggx if len(ctx.needs_input_grad) > 7 and ctx.needs_input_grad[7] else None
+        return g_gy, g_w, None, None, None, None, None, g_resid
+
+
+class DBlockInputFn(Function):
+    """The two consumers of a discriminator block's input x (progressive_gan.py:45-46,52):
+         p1 = conv3x3(leaky_relu(x), W1) + b1          s = AvgPool2d(2) -> conv1x1(Ws)
+    as ONE autograd node, so that their two gradients with respect to x are produced by one kernel: the
+    shortcut's input gradient rides as the residual of conv1's input-gradient convolution instead of autograd
+    adding two full-resolution tensors.  Backward is composed of the Functions above (differentiable again)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, ws, slope, pool_in_conv):
+        pad = (w1.shape[2] - 1) // 2
+        p1 = raw_conv2d(x, w1, pad, pad, bias=b1, in_slope=slope)
+        if pool_in_conv:  # thin layers: conv1x1 -> pool in one launch (the same linear map)
+            xs = None
+            s = raw_conv2d(x, ws, 0, 0, pool=True)
+        else:             # wide layers: the 1x1 GEMM on a quarter of the pixels
+            xs = raw_upfirdn2d(x, _ones_taps(x, 0.25), 1, 2, 0, 0, x.shape[2] // 2, x.shape[3] // 2)
+            s = raw_conv2d(xs, ws, 0, 0)
+        ctx.save_for_backward(x, w1, b1, ws, xs)
+        ctx.cfg = (pad, slope, pool_in_conv)
+        return p1, s
+
+    @staticmethod
+    def backward(ctx, g_p1, g_s):
+        x, w1, b1, ws, xs = ctx.saved_tensors
+        pad, slope, pool_in_conv = ctx.cfg
+        gx = gw1 = gb1 = gws = None
+        if _need(ctx, 0):
+            if pool_in_conv:
+                gx_s = Conv2dDgradFn.apply(g_s, ws, 0, 0, None, 1.0, True)
+            else:
+                gx_s = UpFirDnFn.apply(Conv2dDgradFn.apply(g_s, ws, 0, 0), _ones_taps(x, 0.25), 2, 1, 1, 0, 1, 0)
+            gx = Conv2dDgradFn.apply(g_p1, w1, pad, pad, x, slope, False, gx_s)
+        if _need(ctx, 1):
+            gw1 = Conv2dWgradFn.apply(x, g_p1, w1.shape[2], w1.shape[3], pad, pad, slope, False).to(w1.dtype)
+        if b1 is not None and _need(ctx, 2):
+            gb1 = ChanSumFn.apply(g_p1, False).reshape(b1.shape).to(b1.dtype)
+        if _need(ctx, 3):
+            if pool_in_conv:
+                gws = Conv2dWgradFn.apply(x, g_s, 1, 1, 0, 0, 1.0, True).to(ws.dtype)
+            else:
+                gws = Conv2dWgradFn.apply(xs, g_s, 1, 1, 0, 0).to(ws.dtype)
+        return gx, gw1, gb1, gws, None, None
 
 
 class Conv2dWgradFn(Function):

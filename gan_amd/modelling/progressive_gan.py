@@ -59,14 +59,11 @@ class ProgressiveGanDiscriminatorBlock(nn.Module):
         x = to_act(x)
         act0, conv1, act1, conv2, _ = self.layers
         conv_s = self.shortcut[1]
-        # act -> conv1 (+bias) | act -> conv2 -> pool | conv_s -> pool  (= pool -> conv_s: both are linear
-        # and a 1x1 convolution commutes with the pooling): three launches, no elementwise pass
-        h = GF.conv_bias_act(x, conv1.weight, conv1.bias, conv1.padding[0], 1.0, act0.negative_slope)
+        # act -> conv1 (+bias) and the shortcut (pool -> conv_s; for thin layers conv_s -> pool, the same linear
+        # map, in one launch) share x: one autograd node, so their input gradients come out of one kernel
+        h, s = GF.DBlockInputFn.apply(x, conv1.weight, conv1.bias, conv_s.weight, act0.negative_slope, conv_s.out_channels <= 64)
+        # act -> conv2 -> pool in one launch
         h = GF.Conv2dFn.apply(h, conv2.weight, conv2.padding[0], conv2.padding[1], act1.negative_slope, True)
-        if conv_s.out_channels <= 64:
-            s = GF.Conv2dFn.apply(x, conv_s.weight, 0, 0, 1.0, True)
-        else:  # wide layers: the 1x1 GEMM on a quarter of the pixels beats saving the (small) pooled tensor
-            s = GF.Conv2dFn.apply(GF.avg_pool2(x), conv_s.weight, 0, 0)
         scale = self.scale.reshape(-1)
         bias = conv_s.bias + conv2.bias * scale  # (Cout,) -- three tiny vectors
         return GF.affine_act(h, a=scale, b=bias, r=s)

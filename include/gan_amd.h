@@ -121,11 +121,14 @@ int gan_demod_bwd(const float* g, const float* dinv, const float* s, const float
  *   aux != NULL   : y *= m(aux), m(v) = v > 0 ? 1 : aux_slope, aux shaped like y (the leaky-ReLU derivative
  *                   mask that follows an input gradient);
  *   gain          : scalar factor on the accumulated sum (0.25 for the adjoint of the pooling, whose
- *                   nearest-neighbour upsampling is the up2 gather).  Pass 1, 0, NULL, 1, 1 for none. */
+ *                   nearest-neighbour upsampling is the up2 gather);
+ *   resid != NULL : y += resid (shaped like y) after everything else: the gradient that reaches the same
+ *                   tensor along a second path (the D block's shortcut) without an add pass.
+ * Pass 1, 0, NULL, 1, 1, NULL for none. */
 int gan_conv2d_fwd(const void* x, const void* wt, void* y, const float* in_scale, const float* out_scale,
                    const float* bias, const void* noise, const float* noise_scale, float slope, int N, int H, int W,
                    int Cin, int up2, int Ho, int Wo, int Cout, int kh, int kw, int py, int px, int Kpad,
-                   float in_slope, int pool, const void* aux, float aux_slope, float gain, int dtype,
+                   float in_slope, int pool, const void* aux, float aux_slope, float gain, const void* resid, int dtype,
                    gan_stream_t stream);
 
 /* Weight gradient (autograd of the convolutions above):
