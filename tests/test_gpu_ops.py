@@ -567,3 +567,24 @@ def test_demod_kernels(dev, shape):
     assert rel_err(got, ref) < TOL32
     gs, gw = torch.autograd.grad((got * cot.to(dev)).sum(), [sg, wg])
     assert rel_err(gs, gs_ref) < TOL32 and rel_err(gw, gw_ref) < TOL32
+
+
+@pytest.mark.parametrize("case", [(2, 16, 64, 64, 16, 3), (2, 32, 40, 48, 64, 3), (3, 128, 16, 16, 256, 3), (2, 24, 6, 10, 40, 3)])
+def test_conv2d_dgrad_mask_residual(dev, case):
+    """Input-gradient kernel with the activation mask and the residual add fused (thin DA mode, LDS-DMA
+    kernel, register-staged kernel): gx = m(x) * dgrad(gy, W) + resid."""
+    import gan_amd.functional as GF
+
+    n, cin, h, w, cout, k = case
+    pad = (k - 1) // 2
+    torch.manual_seed(51)
+    gy = torch.randn(n, cout, h, w).bfloat16()
+    x = torch.randn(n, cin, h, w).bfloat16()
+    resid = torch.randn(n, cin, h, w).bfloat16()
+    wgt = (torch.randn(cout, cin, k, k) / (cout * k * k) ** 0.5).bfloat16().float()
+    ref = torch.nn.grad.conv2d_input((n, cin, h, w), wgt.double(), gy.double(), padding=pad)
+    ref = ref * torch.where(x.double() > 0, 1.0, 0.2) + resid.double()
+    got = GF.raw_conv2d_dgrad(gy.to(dev), wgt.to(dev), pad, pad, aux=x.to(dev), aux_slope=0.2, resid=resid.to(dev))
+    assert rel_err(got, ref) < 4e-3, rel_err(got, ref)
+    got32 = GF.raw_conv2d_dgrad(gy.float().to(dev), wgt.to(dev), pad, pad, aux=x.float().to(dev), aux_slope=0.2, resid=resid.float().to(dev))
+    assert rel_err(got32, ref) < TOL32, rel_err(got32, ref)
