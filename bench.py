@@ -275,6 +275,7 @@ def main():
                 "parallelism": f"dp{world}",
                 "losses_finite": finite,
                 "peak_mem_gib": round(peak_mem, 1),
+                "hip_graph": bool(cfg.hip_graph and trainer._graph is not None),
             },
             "roofline": roof,
             "kernels": fams,
