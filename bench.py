@@ -237,6 +237,7 @@ def main():
     logs = trainer.train_step(next_reals)  # sanity: losses stay finite
     finite = all(bool(torch.isfinite(v).all()) for v in logs.values())
     peak_mem = torch.cuda.max_memory_allocated(device) / 2**30
+    graphed = bool(cfg.hip_graph and trainer._graph is not None)
 
     roof = fams = micro_res = cpu = None
     if rank == 0:
@@ -275,7 +276,7 @@ def main():
                 "parallelism": f"dp{world}",
                 "losses_finite": finite,
                 "peak_mem_gib": round(peak_mem, 1),
-                "hip_graph": bool(cfg.hip_graph and trainer._graph is not None),
+                "hip_graph": graphed,
             },
             "roofline": roof,
             "kernels": fams,

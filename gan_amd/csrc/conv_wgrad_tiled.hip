@@ -54,14 +54,18 @@ __device__ __forceinline__ bf16x8 tr_frag2(const char* plo, const char* phi) {
     return f;
 }
 
-constexpr int TW_LOADERS = 2;  // producer waves (waves 3, 4); waves 0-2 are MFMA consumers
+#ifndef GAN_TW_LOADERS
+#define GAN_TW_LOADERS 4
+#endif
+constexpr int TW_LOADERS = GAN_TW_LOADERS;  // producer waves (waves 3..6); waves 0-2 are MFMA consumers
+constexpr int TW_THREADS = 192 + 64 * TW_LOADERS;
 
 
 // Tile geometry is a template parameter: the producers turn a chunk index into (image, row, column) with
 // divisions by HALO and HWD for every 16-byte load, which as run-time divisions made them VALU-bound
 // (PMC: consumers waited 67 % of their cycles on the stage barrier).
 template <int KS, int TWL, int THL, int NBL, bool MOD>
-__global__ void __launch_bounds__(320) conv_wgrad_tiled_k(const TWArgs p) {
+__global__ void __launch_bounds__(TW_THREADS) conv_wgrad_tiled_k(const TWArgs p) {
     extern __shared__ __attribute__((aligned(256))) char tw_lds[];
     constexpr int NT = KS;  // taps (dx) per consumer wave
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -251,7 +255,7 @@ __global__ void __launch_bounds__(320) conv_wgrad_tiled_k(const TWArgs p) {
         }
         __syncthreads();
         float* __restrict__ slice = p.ws + (int64_t)s * p.Cout * p.Cin;
-        for (int e = tid; e < 4096; e += 320) {
+        for (int e = tid; e < 4096; e += TW_THREADS) {
             const int co = co0 + (e >> 6), ci = ci0 + (e & 63);
             if (co < p.Cout && ci < p.Cin) slice[(int64_t)co * p.Cin + ci] = red[e] + red[4096 + e] + red[8192 + e];
         }
@@ -309,7 +313,7 @@ TiledPlan plan_tiled(int N, int Ho, int Wo, int Cin, int Cout, int ks) {
     pl.co_tiles = (Cout + 63) / 64;
     pl.ci_tiles = (Cin + 63) / 64;
     const int ct = pl.co_tiles * pl.ci_tiles;
-    int S = (256 + ct - 1) / ct;  // one 5-wave workgroup per CU (two LDS stages, 256-register consumers)
+    int S = (256 + ct - 1) / ct;  // one 7-wave workgroup per CU (two LDS stages, 256-register consumers)
     if (S > pl.ntiles) S = pl.ntiles;
     if (S > 65535) S = 65535;
     pl.S = S;
@@ -349,9 +353,9 @@ int gan_conv2d_wgrad_tiled(const void* x, const void* gy, float* dw, const float
 #define TW_LAUNCH(KS_, TWL_, THL_, NBL_)                                                                                \
     do {                                                                                                             \
         if (in_scale)                                                                                                \
-            hipLaunchKernelGGL((conv_wgrad_tiled_k<KS_, TWL_, THL_, NBL_, true>), grid, dim3(320), (size_t)pl.lds, st, a);  \
+            hipLaunchKernelGGL((conv_wgrad_tiled_k<KS_, TWL_, THL_, NBL_, true>), grid, dim3(TW_THREADS), (size_t)pl.lds, st, a);  \
         else                                                                                                         \
-            hipLaunchKernelGGL((conv_wgrad_tiled_k<KS_, TWL_, THL_, NBL_, false>), grid, dim3(320), (size_t)pl.lds, st, a); \
+            hipLaunchKernelGGL((conv_wgrad_tiled_k<KS_, TWL_, THL_, NBL_, false>), grid, dim3(TW_THREADS), (size_t)pl.lds, st, a); \
     } while (0)
     if (kh == 3) {
         if (pl.tw_log2 == 5) TW_LAUNCH(3, 5, 2, 0);
