@@ -26,6 +26,7 @@ struct TWArgs {
     int N, H, W, Hl, Wl, up2, Ho, Wo, Cin, Cout, py, px;
     int tiles_x, tiles_y;           // per image (NB == 1)
     int ntiles, S, ci_tiles;
+    unsigned x_bytes, gy_bytes;
     WgradFuse fu;
 };
 
@@ -84,47 +85,57 @@ __global__ void __launch_bounds__(TW_THREADS) conv_wgrad_tiled_k(const TWArgs p)
 
     if (wave >= 3) {
         // ================= producers: tile t -> LDS stage (t - t0) & 1, TW_U loads in flight per lane ====
-        const bf16* __restrict__ x = (const bf16*)p.x;
-        const bf16* __restrict__ gy = (const bf16*)p.gy;
+        typedef unsigned v4u __attribute__((ext_vector_type(4)));
+        constexpr unsigned INV = 0x80000000u;  // past num_records (tensors < 2^31 bytes): the load returns zeros
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, p.x_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.gy), 0, p.gy_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in_scale), 0, MOD ? (unsigned)(p.N * p.Cin) * 4u : 0u, 0x00020000);
         const int ltid = tid - 192;
+        constexpr int PL = 64 * TW_LOADERS;
         constexpr int nxc = ((NPX + 7) >> 3) * 64;  // x chunks (8 pixels x 8 channel chunks per 64)
-        constexpr int ntot = nxc + 128 * 8;         // + gy chunks
-        // Branch-free, division-free staging.  Chunk slot `sl` of this lane (idx = sl * 128 + ltid) always
-        // maps to the same (x | gy, image b, row, col, channel chunk) of a tile, so that decode is done ONCE
-        // here and kept packed in a register per slot; per tile a slot costs ~20 VALU ops, one unconditional
-        // 16-byte load (ld16_or_zero) and one unconditional LDS store (chunks past the image go to a per-lane
-        // dump slot behind the two stages).  History: with `if`s around the loads hipcc emitted a branch and a
-        // vmcnt wait per load, and with run-time divisions ~115 VALU ops per load; either way the producers took
-        // 3x as long as the consumers' MFMAs (ablation: 299 us loads only vs 104 us MFMAs only).
-        constexpr int NSLOT = (ntot + 64 * TW_LOADERS - 1) / (64 * TW_LOADERS);
-        constexpr int U = MOD ? 7 : 14;  // loads in flight per lane and batch
-        int packed[NSLOT], dsto[NSLOT];
+        // Branch-free, division-free staging.  Slot `sl` of this lane always maps to the same (image b, row,
+        // col, channel chunk) of a tile; slots [0, NSX) are x chunks and [NSX, NSLOT) gy chunks, so which
+        // tensor a slot reads is known at compile time.  Tile origins are even, which makes the source
+        // offset LINEAR in the tile origin even through the 2x gathers ((o + r) >> 1 = (o >> 1) + (r >> 1)
+        // for even o): decoded ONCE here into rel[] (byte offset from the tile's base) and packed[] (halo
+        // coordinates for the bounds test), a slot then costs ~10 VALU ops per tile, one buffer load (lanes
+        // past the image read zeros at offset INV) and one LDS store (chunks past the tile go to a per-lane
+        // dump slot behind the two stages).  History: `if`s around the loads cost a branch and a vmcnt wait per
+        // load, run-time divisions ~115 VALU ops per load, the full offset arithmetic per tile ~40 (the
+        // producers, not the MFMAs, set the pace: 2 -> 4 producer waves gave 1.3-1.5x).
+        constexpr int NSX = (nxc + PL - 1) / PL, NSG = (128 * 8 + PL - 1) / PL, NSLOT = NSX + NSG;
+        constexpr int U = MOD ? 7 : NSLOT;  // loads in flight per lane and batch
+        int packed[NSLOT], dsto[NSLOT], rel[NSLOT];
         const int c8l = (ltid >> 3) & 7;  // channel chunk: the same for every slot of a lane
+        const int cix = ci0 + c8l * 8, cog = co0 + c8l * 8;
+        const int shx = p.up2, shg = p.fu.gy_up2;
+        const int Hg = p.Ho >> shg, Wg = p.Wo >> shg;
 #pragma unroll
         for (int sl = 0; sl < NSLOT; ++sl) {
-            const int idx = sl * 64 * TW_LOADERS + ltid;
-            const bool isx = idx < nxc;
-            const int j = isx ? idx : idx - nxc;
-            const int pix = (j >> 6) * 8 + (j & 7);
+            const bool isx = sl < NSX;
+            const int idx = (isx ? sl : sl - NSX) * PL + ltid;
+            const int pix = (idx >> 6) * 8 + (idx & 7);
             int bb, yy, xx, okc, d;
             if (isx) {
                 bb = pix / HALO;
                 const int r = pix - bb * HALO;
                 yy = r / HWD;
                 xx = r - yy * HWD;
-                okc = pix < NPX && ci0 + c8l * 8 < p.Cin;
+                okc = pix < NPX && cix < p.Cin;
                 d = pix < NPX ? (c8l >> 1) * PLX + pix * 32 + (c8l & 1) * 16 : -1;
+                rel[sl] = (((bb * p.H + ((yy - p.py) >> shx)) * p.W + ((xx - p.px) >> shx)) * p.Cin + cix) * 2;
             } else {
                 bb = pix >> thw_log2;
                 yy = (pix >> TWL) & (TH - 1);
                 xx = pix & (TW - 1);
-                okc = idx < ntot && co0 + c8l * 8 < p.Cout;
-                d = idx < ntot ? 4 * PLX + (c8l >> 1) * PLG + pix * 32 + (c8l & 1) * 16 : -1;
+                okc = idx < 128 * 8 && cog < p.Cout;
+                d = idx < 128 * 8 ? 4 * PLX + (c8l >> 1) * PLG + pix * 32 + (c8l & 1) * 16 : -1;
+                rel[sl] = (((bb * Hg + (yy >> shg)) * Wg + (xx >> shg)) * p.Cout + cog) * 2;
             }
-            packed[sl] = yy | (xx << 8) | (bb << 16) | ((isx ? 1 : 0) << 24) | (okc << 25);
+            packed[sl] = yy | (xx << 8) | (bb << 16) | (okc << 25);
             dsto[sl] = d;
         }
-        const int cix = ci0 + c8l * 8, cog = co0 + c8l * 8;
         for (int t = t0; t < t1; ++t) {
             char* const xl = tw_lds + ((t - t0) & 1) * BUF;
             int n0, oy0, ox0;
@@ -138,46 +149,48 @@ __global__ void __launch_bounds__(TW_THREADS) conv_wgrad_tiled_k(const TWArgs p)
                 n0 = t * NB;
                 oy0 = ox0 = 0;
             }
+            // wave-uniform bases of the tile (bytes)
+            const int bx = ((n0 * p.H + (oy0 >> shx)) * p.W + (ox0 >> shx)) * p.Cin * 2;
+            const int bg = ((n0 * Hg + (oy0 >> shg)) * Wg + (ox0 >> shg)) * p.Cout * 2;
             const int dump = 2 * BUF + ltid * 16 - ((t - t0) & 1) * BUF;
 #pragma unroll
             for (int b0 = 0; b0 < NSLOT; b0 += U) {
-                uint4 v[U];
-                float4 s0[MOD ? U : 1], s1[MOD ? U : 1];
+                v4u v[U];
+                v4u s0[MOD ? U : 1], s1[MOD ? U : 1];
 #pragma unroll
                 for (int k = 0; k < U; ++k) {
                     if (b0 + k < NSLOT) {
-                        const int pk = packed[b0 + k];
-                        const bool isx = (pk >> 24) & 1;
+                        const bool isx = b0 + k < NSX;
+                        int pk = packed[b0 + k];
+                        asm volatile("" : "+v"(pk));  // keeps the decode below out of the tile loop's preheader (registers)
                         const int nn = n0 + ((pk >> 16) & 0xff);
                         const int y = (isx ? oy0 - p.py : oy0) + (pk & 0xff);
                         const int xq = (isx ? ox0 - p.px : ox0) + ((pk >> 8) & 0xff);
                         const bool ok = ((pk >> 25) & 1) && nn < p.N && (unsigned)y < (unsigned)(isx ? p.Hl : p.Ho) &&
                                         (unsigned)xq < (unsigned)(isx ? p.Wl : p.Wo);
-                        const int sh = isx ? p.up2 : p.fu.gy_up2;  // gy_up2: gy is stored at half resolution
-                        const int off = ((nn * (isx ? p.H : p.Ho >> sh) + (y >> sh)) * (isx ? p.W : p.Wo >> sh) + (xq >> sh)) * (isx ? p.Cin : p.Cout) +
-                                        (isx ? cix : cog);
-                        v[k] = ld16_or_zero(isx ? (const void*)x : (const void*)gy, (int64_t)off * 2, ok);
-                        if (MOD) {
-                            const float* sp = p.in_scale + ((isx && ok) ? nn * p.Cin + cix : 0);
-                            const float4 a0 = *reinterpret_cast<const float4*>(sp);
-                            const float4 a1 = *reinterpret_cast<const float4*>(sp + 4);
-                            const float4 one = make_float4(1.f, 1.f, 1.f, 1.f);
-                            s0[k] = isx ? a0 : one;
-                            s1[k] = isx ? a1 : one;
+                        const unsigned off = ok ? (unsigned)((isx ? bx : bg) + rel[b0 + k]) : INV;
+                        v[k] = __builtin_amdgcn_raw_buffer_load_b128(isx ? rx : rg, off, 0, 0);
+                        if (MOD && isx) {
+                            const unsigned so = ok ? (unsigned)(nn * p.Cin + cix) * 4u : INV;
+                            s0[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, so, 0, 0);
+                            s1[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, so + 16u, 0, 0);
                         }
                     }
                 }
 #pragma unroll
                 for (int k = 0; k < U; ++k) {
                     if (b0 + k < NSLOT) {
-                        uint4 u = v[k];
-                        if (p.fu.x_slope != 1.f) u = lrelu_chunk(u, ((packed[b0 + k] >> 24) & 1) ? p.fu.x_slope : 1.f, bf16());
-                        if (MOD) {
+                        const bool isx = b0 + k < NSX;
+                        uint4 u = make_uint4(v[k][0], v[k][1], v[k][2], v[k][3]);
+                        if (isx && p.fu.x_slope != 1.f) u = lrelu_chunk(u, p.fu.x_slope, bf16());
+                        if (MOD && isx) {
                             bf16x8 h = *reinterpret_cast<bf16x8*>(&u);
-                            h[0] = (bf16)((float)h[0] * s0[k].x); h[1] = (bf16)((float)h[1] * s0[k].y);
-                            h[2] = (bf16)((float)h[2] * s0[k].z); h[3] = (bf16)((float)h[3] * s0[k].w);
-                            h[4] = (bf16)((float)h[4] * s1[k].x); h[5] = (bf16)((float)h[5] * s1[k].y);
-                            h[6] = (bf16)((float)h[6] * s1[k].z); h[7] = (bf16)((float)h[7] * s1[k].w);
+                            const float4 a0 = *reinterpret_cast<const float4*>(&s0[k]);
+                            const float4 a1 = *reinterpret_cast<const float4*>(&s1[k]);
+                            h[0] = (bf16)((float)h[0] * a0.x); h[1] = (bf16)((float)h[1] * a0.y);
+                            h[2] = (bf16)((float)h[2] * a0.z); h[3] = (bf16)((float)h[3] * a0.w);
+                            h[4] = (bf16)((float)h[4] * a1.x); h[5] = (bf16)((float)h[5] * a1.y);
+                            h[6] = (bf16)((float)h[6] * a1.z); h[7] = (bf16)((float)h[7] * a1.w);
                             u = *reinterpret_cast<uint4*>(&h);
                         }
                         const int d = dsto[b0 + k];
@@ -330,7 +343,7 @@ TiledPlan plan_tiled(int N, int Ho, int Wo, int Cin, int Cout, int ks) {
 int64_t gan_wgrad_tiled_workspace(int N, int Ho, int Wo, int Cin, int Cout, int kh, int kw, int py, int px) {
     if (kh != kw || (kh != 1 && kh != 3) || py != (kh - 1) / 2 || px != py) return 0;
     if ((Cin & 7) || (Cout & 7)) return 0;
-    if ((int64_t)N * Ho * Wo * (Cin > Cout ? Cin : Cout) >= (1LL << 31)) return 0;  // 32-bit element offsets in the producers
+    if ((int64_t)N * Ho * Wo * (Cin > Cout ? Cin : Cout) >= (1LL << 30)) return 0;  // 32-bit byte offsets, INV past the end
     const TiledPlan pl = plan_tiled(N, Ho, Wo, Cin, Cout, kh);
     if (!pl.ok) return 0;
     return (int64_t)pl.S * kh * kw * Cout * Cin;
@@ -348,6 +361,8 @@ int gan_conv2d_wgrad_tiled(const void* x, const void* gy, float* dw, const float
     a.x = x; a.gy = gy; a.ws = ws; a.in_scale = in_scale;
     a.N = N; a.H = H; a.W = W; a.Hl = up2 ? 2 * H : H; a.Wl = up2 ? 2 * W : W; a.up2 = up2;
     a.Ho = Ho; a.Wo = Wo; a.Cin = Cin; a.Cout = Cout; a.py = py; a.px = px;
+    a.x_bytes = (unsigned)((int64_t)N * H * W * Cin * 2);
+    a.gy_bytes = (unsigned)(((int64_t)N * (Ho >> fu.gy_up2) * (Wo >> fu.gy_up2)) * Cout * 2);
     a.tiles_x = pl.tiles_x; a.tiles_y = pl.tiles_y; a.ntiles = pl.ntiles; a.S = pl.S; a.ci_tiles = pl.ci_tiles;
     const dim3 grid((unsigned)(pl.co_tiles * pl.ci_tiles), (unsigned)pl.S);
 #define TW_LAUNCH(KS_, TWL_, THL_, NBL_)                                                                                \
