@@ -811,6 +811,54 @@ extern "C" int gan_pack_weight(const void* w, int w_dtype, void* out, int out_dt
 }
 
 
+// ---- image-like tensors (C < 8: RGB) -> channels-last, channel-padded, compute dtype ------------
+// out[n][h][w][0..Cp) = x[n][c][h][w] for c < C, zeros above; x has arbitrary element strides (NCHW or
+// channels-last, fp32 or bf16).  One pass instead of cast + layout copy + zero fill + strided copy (the
+// from-RGB / to-RGB tensors are the largest in the model: 0.5 GB padded at 256x256, batch 256).
+// Block = one image row; a thread writes one 8-channel chunk of a pixel (16 B in bf16).
+template <typename TI, typename TO>
+__global__ void __launch_bounds__(256) pad_channels_k(const TI* __restrict__ x, int64_t sn, int64_t sc, int64_t sh, int64_t sw,
+                                                      TO* __restrict__ out, int H, int W, int C, int Cp) {
+    const int row = blockIdx.x;  // n * H + h
+    const int n = row / H, h = row - n * H;
+    const TI* __restrict__ src = x + (int64_t)n * sn + (int64_t)h * sh;
+    TO* __restrict__ dst = out + (int64_t)row * W * Cp;
+    const int chunks = Cp >> 3;
+    for (int e = threadIdx.x; e < W * chunks; e += 256) {
+        const int w = e / chunks, c0 = (e - w * chunks) * 8;
+        TO v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (TO)(c0 + j < C ? (float)src[(int64_t)w * sw + (int64_t)(c0 + j) * sc] : 0.f);
+        TO* o = dst + (int64_t)e * 8;
+        if (sizeof(TO) == 2) {
+            *reinterpret_cast<uint4*>(o) = *reinterpret_cast<const uint4*>(v);
+        } else {
+            *reinterpret_cast<uint4*>(o) = *reinterpret_cast<const uint4*>(v);
+            *reinterpret_cast<uint4*>(o + 4) = *reinterpret_cast<const uint4*>(v + 4);
+        }
+    }
+}
+
+extern "C" int gan_pad_channels(const void* x, int x_dtype, int64_t sn, int64_t sc, int64_t sh, int64_t sw, void* out, int out_dtype,
+                                int N, int C, int H, int W, int Cp, gan_stream_t stream) {
+    GAN_CHECK_ARG(x && out, "pad_channels: null pointer");
+    GAN_CHECK_ARG((x_dtype == GAN_F32 || x_dtype == GAN_BF16) && (out_dtype == GAN_F32 || out_dtype == GAN_BF16), "pad_channels: bad dtype");
+    GAN_CHECK_ARG(N > 0 && C > 0 && H > 0 && W > 0 && Cp >= C && (Cp & 7) == 0, "pad_channels: bad shape (Cp must be a multiple of 8, >= C)");
+    GAN_CHECK_ARG((int64_t)N * H < (1LL << 31) && (int64_t)W * (Cp >> 3) < (1LL << 31), "pad_channels: too large");
+    GAN_CHECK_ARG(((uintptr_t)out % 16) == 0, "pad_channels: output must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+#define PADC_LAUNCH(TI, TO) \
+    hipLaunchKernelGGL((pad_channels_k<TI, TO>), dim3((unsigned)(N * H)), dim3(256), 0, st, (const TI*)x, sn, sc, sh, sw, (TO*)out, H, W, C, Cp)
+    if (x_dtype == GAN_F32 && out_dtype == GAN_BF16) PADC_LAUNCH(float, bf16);
+    else if (x_dtype == GAN_F32) PADC_LAUNCH(float, float);
+    else if (out_dtype == GAN_BF16) PADC_LAUNCH(bf16, bf16);
+    else PADC_LAUNCH(bf16, float);
+#undef PADC_LAUNCH
+    GAN_CHECK_LAUNCH("pad_channels");
+    return GAN_OK;
+}
+
+
 // =========================================================================================
 // Demodulation factor of ModulatedConv2d (reference: F.normalize(weight * s, dim=(2,3,4), eps=1e-8),
 // modelling/stylegan2.py:33) without the (N, Cout, Cin, k, k) tensor:

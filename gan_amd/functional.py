@@ -287,20 +287,35 @@ def raw_scale_dot(A: Tensor, B: Tensor, a: Tensor):
 _PAD_MEMO: dict = {}
 
 
-def _pad_channels(x: Tensor, mult: int) -> Tensor:
+def _pad_channels(x: Tensor, mult: int, dtype: Optional[torch.dtype] = None) -> Tensor:
+    """Channels-last x with the channel count padded to a multiple of `mult` (zeros), in `dtype` (default x's)."""
     c = x.shape[1]
+    dtype = dtype or x.dtype
     rem = (-c) % mult
-    if rem == 0:
-        return as_cl(x)
     if c < 8:  # image-like input: pad once to 16 for both users (conv forward wants 8, weight gradient 16)
-        rem = 16 - c
-        key = (x.data_ptr(), x._version, tuple(x.shape), tuple(x.stride()), x.dtype)
+        key = (x.data_ptr(), x._version, tuple(x.shape), tuple(x.stride()), x.dtype, dtype)
         hit = _PAD_MEMO.get("last")
         if hit is not None and hit[0] == key:
             return hit[2]
-        out = as_cl(F.pad(x, (0, 0, 0, 0, 0, rem)))
+        if x.dim() != 4:
+            raise _lib.GanAmdError(f"expected a 4-D (N, C, H, W) tensor, got shape {tuple(x.shape)}")
+        n, _, h, w = x.shape
+        out = torch.empty((n, 16, h, w), dtype=dtype, device=x.device, memory_format=CL)
+        sn, sc, sh, sw = x.stride()
+        check(
+            _run(
+                "pad_channels", 0, _nbytes(x, out),
+                lambda: _lib.load().gan_pad_channels(ptr(x), dtype_code(x), sn, sc, sh, sw, ptr(out), dtype_code(out), n, c, h, w, 16, stream_of(x)),
+                (n, c, h, w),
+            ),
+            "gan_pad_channels",
+        )
         _PAD_MEMO["last"] = (key, x, out)  # x is held: its storage cannot be recycled under the same key
         return out
+    if x.dtype != dtype:
+        x = x.to(dtype)
+    if rem == 0:
+        return as_cl(x)
     return as_cl(F.pad(x, (0, 0, 0, 0, 0, rem)))
 
 

@@ -18,8 +18,8 @@ def to_act(x: Tensor) -> Tensor:
     dt = GF.act_dtype(x)
     if dt not in (torch.float32, torch.bfloat16):
         raise GF._lib.GanAmdError(f"unsupported compute dtype {dt}: the kernels take float32 or bfloat16")
-    if x.dtype != dt:
-        x = x.to(dt)
+    if x.dtype != dt:  # cast and layout change in one copy
+        return x.to(dtype=dt, memory_format=torch.channels_last)
     return x.contiguous(memory_format=torch.channels_last)
 
 

@@ -156,6 +156,14 @@ int gan_conv2d_wgrad(const void* x, const void* gy, float* dw, const float* in_s
 int gan_pack_weight(const void* w, int w_dtype, void* out, int out_dtype, int Cout, int Cin, int kh, int kw, int cols_p,
                     int Kpad, int transposed, gan_stream_t stream);
 
+/* Image-like tensors (C < 8: the RGB inputs / outputs of the from-RGB and to-RGB convolutions,
+ * progressive_gan.py:61, stylegan2.py:124) -> channels-last, zero padded to Cp channels (multiple of 8), in
+ * out_dtype: out[n][h][w][c] = x[n*sn + c*sc + h*sh + w*sw] (element strides; NCHW or channels-last, fp32 or
+ * bf16).  Host-side glue of the reference (F.conv2d takes 3 channels as they are); one pass instead of
+ * cast + layout copy + zero fill + strided copy. */
+int gan_pad_channels(const void* x, int x_dtype, int64_t sn, int64_t sc, int64_t sh, int64_t sw, void* out, int out_dtype,
+                     int N, int C, int H, int W, int Cp, gan_stream_t stream);
+
 /* ---- MinibatchStdDev ---------------------------------------------------------------------
  * replaces MinibatchStdDev.forward   modelling/progressive_gan.py:20-36
  * stat[j] = mean_{c,h,w} sqrt( var_k x[j + k*M] + 1e-6 ),  M = N/G, population variance over the

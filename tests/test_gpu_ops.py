@@ -588,3 +588,29 @@ def test_conv2d_dgrad_mask_residual(dev, case):
     assert rel_err(got, ref) < 4e-3, rel_err(got, ref)
     got32 = GF.raw_conv2d_dgrad(gy.float().to(dev), wgt.to(dev), pad, pad, aux=x.float().to(dev), aux_slope=0.2, resid=resid.float().to(dev))
     assert rel_err(got32, ref) < TOL32, rel_err(got32, ref)
+
+
+@pytest.mark.parametrize("in_dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("out_dtype", [torch.float32, torch.bfloat16])
+def test_pad_channels_kernel(dev, in_dtype, out_dtype):
+    """gan_pad_channels: image-like tensors of any stride pattern -> channels-last, 16 channels, compute dtype.
+    Bit-exact against cast + F.pad (the cast is the only arithmetic)."""
+    import gan_amd.functional as GF
+
+    g = torch.Generator().manual_seed(3)
+    base = torch.randn(3, 5, 17, 40, generator=g).to(dev).to(in_dtype)
+    views = [
+        base[:, :3],                                                        # NCHW slice (batch stride != C*H*W)
+        base[:, 1:2],                                                       # one channel
+        base[:, :3].contiguous(memory_format=torch.channels_last),          # channels-last
+        base.permute(0, 1, 3, 2)[:, :3],                                    # transposed rows / columns
+        base[:, :3, ::2, 1::3],                                             # strided in h and w
+    ]
+    for x in views:
+        GF._PAD_MEMO.clear()
+        out = GF._pad_channels(x, 8, out_dtype)
+        ref = F.pad(x.to(out_dtype), (0, 0, 0, 0, 0, 16 - x.shape[1]))
+        assert out.shape == ref.shape and out.dtype == out_dtype
+        assert out.is_contiguous(memory_format=torch.channels_last)
+        assert torch.equal(out, ref)
+        assert GF._pad_channels(x, 16, out_dtype) is out  # memo: the weight gradient pads the same tensor
