@@ -154,17 +154,24 @@ struct WgradFuse {
     float gain;
 };
 
-// conv_thin_wgrad.hip: weight gradient for thin layers (bf16); dw must be zeroed by the caller.
-int gan_conv2d_wgrad_thin(const void* x, const void* gy, float* dw, const float* in_scale, int N, int H, int W,
+// Where a weight gradient ends up: fp32 (cout, cin, kh, kw), the parameter's own layout, without the channel
+// padding of the kernels' operands.
+struct DwOut {
+    float* out;
+    int cout, cin;
+};
+
+// conv_thin_wgrad.hip: weight gradient for thin layers (bf16, needs the workspace it reports through `need`).
+int gan_conv2d_wgrad_thin(const void* x, const void* gy, const DwOut& dwo, const float* in_scale, int N, int H, int W,
                           int Cin, int up2, int Ho, int Wo, int Cout, int kh, int kw, int py, int px, float* ws,
                           int64_t ws_floats, int64_t* need, const WgradFuse& fu, hipStream_t st);
 // conv_wgrad_tiled.hip: weight gradient for wide layers / small maps (bf16, needs a workspace) and the
-// slice reducer out[e] += sum_s ws[s][e].
+// slice reducer: dwo.out[co][ci][tap] = gain * sum_s ws[s][tap][co][ci] (ws: S slices of taps x Cout x Cin).
 int64_t gan_wgrad_tiled_workspace(int N, int Ho, int Wo, int Cin, int Cout, int kh, int kw, int py, int px);
-int gan_conv2d_wgrad_tiled(const void* x, const void* gy, float* dw, const float* in_scale, int N, int H, int W,
+int gan_conv2d_wgrad_tiled(const void* x, const void* gy, const DwOut& dwo, const float* in_scale, int N, int H, int W,
                            int Cin, int up2, int Ho, int Wo, int Cout, int kh, int kw, int py, int px, float* ws,
                            int64_t ws_floats, const WgradFuse& fu, hipStream_t st);
-int gan_reduce_slices(const float* ws, float* out, int64_t L, int S, float gain, hipStream_t st);
+int gan_finalize_dw(const float* ws, int S, int taps, int Cout, int Cin, const DwOut& dwo, float gain, hipStream_t st);
 
 // upfirdn_mfma.hip: bf16 upfirdn2d with the FIR as banded matrix products on MFMA.  1 / 0 / < 0 as above.
 int gan_upfirdn2d_mfma(const void* x, const float* taps, void* y, int N, int H, int W, int C, int ky, int kx, int up,

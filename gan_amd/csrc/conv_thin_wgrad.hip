@@ -29,6 +29,7 @@ struct ThinWArgs {
     float* ws;  // optional [gridDim.x * WR][taps][Cout][Cin] partial slices (plain stores) instead of atomics
     unsigned x_bytes, g_bytes;  // < 2^31: 32-bit buffer offsets
     WgradFuse fu;
+    DwOut dwo;  // host side only: where the slice reducer writes
 };
 
 __device__ __forceinline__ uint4 wmod_chunk(uint4 raw, const float* s) {
@@ -83,8 +84,6 @@ __global__ void __launch_bounds__(256, 2) conv_thin_wgrad_k(const ThinWArgs p) {
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wt = wave % WT, wr = wave / WT;
-    const bf16* __restrict__ x = (const bf16*)p.x;
-    const bf16* __restrict__ gy = (const bf16*)p.gy;
 
     const int tiles_per_img = p.tiles_x * p.tiles_y;
     const int ntiles = tiles_per_img * p.N;
@@ -264,12 +263,10 @@ int launch_thin_w(ThinWArgs a, int64_t ws_floats, int64_t* need, hipStream_t st)
         *need = want;
         return GAN_OK;
     }
-    const bool use_ws = a.ws != nullptr && ws_floats >= want && (L & 3) == 0;
-    if (!use_ws) a.ws = nullptr;
+    if (a.ws == nullptr || ws_floats < want) return 1;  // not served without its slices (GAN_OK is 0; the caller maps 1 -> 0)
     hipLaunchKernelGGL((conv_thin_wgrad_k<CIN, COUT, KS, TH, WT>), dim3((unsigned)grid), dim3(256), 0, st, a);
     GAN_CHECK_LAUNCH("conv2d_wgrad(thin)");
-    if (use_ws) return gan_reduce_slices(a.ws, a.dw, L, (int)(grid * C::WR), a.fu.gain, st);
-    return GAN_OK;
+    return gan_finalize_dw(a.ws, (int)(grid * C::WR), KS * KS, a.Cout, a.Cin, a.dwo, a.fu.gain, st);
 }
 
 template <int CIN, int COUT>
@@ -290,9 +287,9 @@ int pick_cout_w(const ThinWArgs& a, int ks, int64_t wsf, int64_t* need, hipStrea
 
 }  // namespace
 
-// 1 = served (dw must already be zeroed), 0 = shape not eligible, < 0 = error.
+// 1 = served, 0 = shape not eligible or workspace too small, < 0 = error.
 // need != nullptr: query only -- *need = workspace floats the launch would like (0 if not eligible).
-int gan_conv2d_wgrad_thin(const void* x, const void* gy, float* dw, const float* in_scale, int N, int H, int W,
+int gan_conv2d_wgrad_thin(const void* x, const void* gy, const DwOut& dwo, const float* in_scale, int N, int H, int W,
                           int Cin, int up2, int Ho, int Wo, int Cout, int kh, int kw, int py, int px, float* ws,
                           int64_t ws_floats, int64_t* need, const WgradFuse& fu, hipStream_t st) {
     if (need) *need = 0;
@@ -305,7 +302,7 @@ int gan_conv2d_wgrad_thin(const void* x, const void* gy, float* dw, const float*
     ThinWArgs a;
     a.x_bytes = (unsigned)xb; a.g_bytes = (unsigned)gb;
     a.fu = fu;
-    a.x = x; a.gy = gy; a.dw = dw; a.in_scale = in_scale;
+    a.x = x; a.gy = gy; a.dw = nullptr; a.dwo = dwo; a.in_scale = in_scale;
     a.N = N; a.H = H; a.W = W; a.Hl = up2 ? 2 * H : H; a.Wl = up2 ? 2 * W : W; a.up2 = up2;
     a.Ho = Ho; a.Wo = Wo; a.Cin = Cin; a.Cout = Cout; a.py = py; a.px = px;
     a.tiles_x = a.tiles_y = 0;
@@ -314,5 +311,5 @@ int gan_conv2d_wgrad_thin(const void* x, const void* gy, float* dw, const float*
     if (Cin <= 16) rc = pick_cout_w<16>(a, kh, ws_floats, need, st);
     else if (Cin <= 32) rc = pick_cout_w<32>(a, kh, ws_floats, need, st);
     else rc = pick_cout_w<64>(a, kh, ws_floats, need, st);
-    return rc == GAN_OK ? 1 : rc;
+    return rc == GAN_OK ? 1 : (rc == 1 ? 0 : rc);
 }

@@ -237,16 +237,18 @@ int launch(const WgradArgs& a, hipStream_t st) {
 
 extern "C" int64_t gan_conv2d_wgrad_workspace(int N, int H, int W, int Cin, int up2, int Ho, int Wo, int Cout, int kh,
                                               int kw, int py, int px, int dtype) {
-    if (dtype != GAN_BF16 || N <= 0) return 0;
+    if (N <= 0 || Cin <= 0 || Cout <= 0 || kh <= 0 || kw <= 0) return 0;
+    const int64_t L = (int64_t)kh * kw * Cout * Cin;  // every path folds at least one padded slice into dw
+    if (dtype != GAN_BF16) return L;
     int64_t need = 0;
-    gan_conv2d_wgrad_thin(nullptr, nullptr, nullptr, nullptr, N, H, W, Cin, up2, Ho, Wo, Cout, kh, kw, py, px, nullptr, 0,
+    gan_conv2d_wgrad_thin(nullptr, nullptr, DwOut{nullptr, 0, 0}, nullptr, N, H, W, Cin, up2, Ho, Wo, Cout, kh, kw, py, px, nullptr, 0,
                           &need, WgradFuse{1.f, 0, 1.f}, nullptr);
-    if (need > 0) return need;
-    return gan_wgrad_tiled_workspace(N, Ho, Wo, Cin, Cout, kh, kw, py, px);
+    if (need == 0) need = gan_wgrad_tiled_workspace(N, Ho, Wo, Cin, Cout, kh, kw, py, px);
+    return need > L ? need : L;
 }
 
-extern "C" int gan_conv2d_wgrad(const void* x, const void* gy, float* dw, const float* in_scale, int N, int H, int W,
-                                int Cin, int up2, int Ho, int Wo, int Cout, int kh, int kw, int py, int px,
+extern "C" int gan_conv2d_wgrad(const void* x, const void* gy, float* dw, int Cout_out, int Cin_out, const float* in_scale, int N,
+                                int H, int W, int Cin, int up2, int Ho, int Wo, int Cout, int kh, int kw, int py, int px,
                                 float* workspace, int64_t workspace_floats, float x_slope, int gy_up2, float gain,
                                 int dtype, gan_stream_t stream) {
     GAN_CHECK_ARG(dw && (N == 0 || (x && gy)), "conv2d_wgrad: null pointer");
@@ -254,9 +256,10 @@ extern "C" int gan_conv2d_wgrad(const void* x, const void* gy, float* dw, const 
     GAN_CHECK_ARG(N >= 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Ho > 0 && Wo > 0, "conv2d_wgrad: bad shape");
     GAN_CHECK_ARG(Cin % 16 == 0 && Cout % 16 == 0, "conv2d_wgrad: Cin=%d and Cout=%d must be multiples of 16 (pad)",
                   Cin, Cout);
+    GAN_CHECK_ARG(Cout_out >= 1 && Cout_out <= Cout && Cin_out >= 1 && Cin_out <= Cin,
+                  "conv2d_wgrad: dw is %d x %d channels, the padded operands have %d x %d", Cout_out, Cin_out, Cout, Cin);
     GAN_CHECK_ARG(kh >= 1 && kw >= 1 && kh * kw <= 64, "conv2d_wgrad: bad kernel %dx%d", kh, kw);
     GAN_CHECK_ARG(up2 == 0 || up2 == 1, "conv2d_wgrad: up2 must be 0 or 1");
-    GAN_CHECK_ARG(workspace_floats >= 0 && (workspace != nullptr || workspace_floats == 0), "conv2d_wgrad: bad workspace");
     const int Hl = up2 ? 2 * H : H, Wl = up2 ? 2 * W : W;
     GAN_CHECK_ARG(Ho == Hl + 2 * py - kh + 1 && Wo == Wl + 2 * px - kw + 1,
                   "conv2d_wgrad: output %dx%d does not match input %dx%d, kernel %dx%d, pad %d,%d", Ho, Wo, Hl, Wl,
@@ -264,29 +267,42 @@ extern "C" int gan_conv2d_wgrad(const void* x, const void* gy, float* dw, const 
     GAN_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)gy % 16) == 0, "conv2d_wgrad: x and gy must be 16-byte aligned");
     GAN_CHECK_ARG(gy_up2 == 0 || (gy_up2 == 1 && Ho % 2 == 0 && Wo % 2 == 0), "conv2d_wgrad: gy_up2 needs an even %dx%d output", Ho, Wo);
     const WgradFuse fu{x_slope, gy_up2, gain};
+    const DwOut dwo{dw, Cout_out, Cin_out};
     hipStream_t st = (hipStream_t)stream;
-    const size_t bytes = sizeof(float) * (size_t)kh * kw * Cout * Cin;
-    if (hipMemsetAsync(dw, 0, bytes, st) != hipSuccess) {
-        gan_set_error("conv2d_wgrad: memset failed");
-        return GAN_ERR_LAUNCH;
+    const int64_t L = (int64_t)kh * kw * Cout * Cin;
+    if (N == 0) {
+        if (hipMemsetAsync(dw, 0, sizeof(float) * (size_t)kh * kw * Cout_out * Cin_out, st) != hipSuccess) {
+            gan_set_error("conv2d_wgrad: memset failed");
+            return GAN_ERR_LAUNCH;
+        }
+        return GAN_OK;
     }
-    if (N == 0) return GAN_OK;
+    const int64_t need = gan_conv2d_wgrad_workspace(N, H, W, Cin, up2, Ho, Wo, Cout, kh, kw, py, px, dtype);
+    GAN_CHECK_ARG(workspace != nullptr && workspace_floats >= need && ((uintptr_t)workspace % 16) == 0,
+                  "conv2d_wgrad: needs a 16-byte aligned workspace of %lld floats (gan_conv2d_wgrad_workspace), got %lld",
+                  (long long)need, (long long)workspace_floats);
     if (dtype == GAN_BF16) {
-        int rc = gan_conv2d_wgrad_thin(x, gy, dw, in_scale, N, H, W, Cin, up2, Ho, Wo, Cout, kh, kw, py, px, workspace,
+        int rc = gan_conv2d_wgrad_thin(x, gy, dwo, in_scale, N, H, W, Cin, up2, Ho, Wo, Cout, kh, kw, py, px, workspace,
                                        workspace_floats, nullptr, fu, st);
         if (rc != 0) return rc < 0 ? rc : GAN_OK;
-        rc = gan_conv2d_wgrad_tiled(x, gy, dw, in_scale, N, H, W, Cin, up2, Ho, Wo, Cout, kh, kw, py, px, workspace,
+        rc = gan_conv2d_wgrad_tiled(x, gy, dwo, in_scale, N, H, W, Cin, up2, Ho, Wo, Cout, kh, kw, py, px, workspace,
                                     workspace_floats, fu, st);
         if (rc != 0) return rc < 0 ? rc : GAN_OK;
     }
+    // register-staged kernel: fp32 atomics into one zeroed, padded slice of the workspace, then the same reducer
+    if (hipMemsetAsync(workspace, 0, sizeof(float) * (size_t)L, st) != hipSuccess) {
+        gan_set_error("conv2d_wgrad: memset failed");
+        return GAN_ERR_LAUNCH;
+    }
     WgradArgs a;
     a.fu = fu;
-    a.x = x; a.gy = gy; a.dw = dw; a.in_scale = in_scale;
+    a.x = x; a.gy = gy; a.dw = workspace; a.in_scale = in_scale;
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Hl = Hl; a.Wl = Wl; a.up2 = up2;
     a.Ho = Ho; a.Wo = Wo; a.Cout = Cout; a.kh = kh; a.kw = kw; a.py = py; a.px = px;
     a.ci_tiles = 1;
     a.M = (int64_t)N * Ho * Wo;
     a.pix_per_split = 128;
-    if (dtype == GAN_F32) return launch<float>(a, st);
-    return launch<bf16>(a, st);
+    const int rc = dtype == GAN_F32 ? launch<float>(a, st) : launch<bf16>(a, st);
+    if (rc != GAN_OK) return rc;
+    return gan_finalize_dw(workspace, 1, kh * kw, Cout, Cin, dwo, 1.f, st);  // the kernel applied the gain
 }

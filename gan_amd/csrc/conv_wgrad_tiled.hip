@@ -12,7 +12,7 @@
 //   * k = 32 consecutive tile-linear pixels per MFMA; both operands are pixel-major, stored as
 //     [16-channel group][pixel][16 ch] and read with ds_read_b64_tr_b16 (per-lane halo offsets);
 //   * split-K over pixel tiles: every workgroup writes its partial tile with plain stores into slice
-//     s of a caller-provided workspace [S][taps][Cout][Cin]; reduce_slices_k folds the slices.
+//     s of a caller-provided workspace [S][taps][Cout][Cin]; finalize_dw_k folds the slices.
 //     (fp32 atomics from ~500 workgroups into one 147 KB tile ran at 0.3 TB/s and dominated.)
 #include "common.h"
 
@@ -275,27 +275,48 @@ __global__ void __launch_bounds__(TW_THREADS) conv_wgrad_tiled_k(const TWArgs p)
     }
 }
 
-// out[e] += sum over a chunk of 32 slices of ws[s][e]   (out zeroed by the caller; few adders per address)
-__global__ void __launch_bounds__(256) reduce_slices_k(const float* __restrict__ ws, float* __restrict__ out, int64_t L,
-                                                       int S, float gain) {
-    const int64_t e4 = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (e4 * 4 >= L) return;
-    const int s0 = blockIdx.y * 32;
-    const int s1 = min(S, s0 + 32);
+// dw[co][ci][tap] = gain * sum_s ws[s][tap][co][ci]: folds the split-K slices and writes the parameter's own
+// layout (cout x cin x taps, channel padding dropped), so the caller needs neither a zeroed target nor a
+// permute / slice copy afterwards.  A block owns 64 quads of consecutive ci; its SG waves split the slices.
+template <int SG>
+__global__ void __launch_bounds__(64 * SG) finalize_dw_k(const float* __restrict__ ws, float* __restrict__ out, int64_t L, int S,
+                                                         int taps, int Cout, int Cin, int cout_o, int cin_o, float gain) {
+    __shared__ float4 part[SG * 64];
+    const int lane = threadIdx.x & 63, sg = threadIdx.x >> 6;
+    const int64_t e4 = (int64_t)blockIdx.x * 64 + lane;
+    const bool live = e4 * 4 < L;
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-    const float* __restrict__ src = ws + e4 * 4;
+    if (live) {
+        const float* __restrict__ src = ws + e4 * 4;
 #pragma unroll 8
-    for (int s = s0; s < s1; ++s) {
-        const float4 v = *reinterpret_cast<const float4*>(src + (int64_t)s * L);
-        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        for (int s = sg; s < S; s += SG) {
+            const float4 v = *reinterpret_cast<const float4*>(src + (int64_t)s * L);
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
     }
-    a.x *= gain; a.y *= gain; a.z *= gain; a.w *= gain;
-    float* o = out + e4 * 4;
-    if (gridDim.y == 1) {
-        *reinterpret_cast<float4*>(o) = a;
-    } else {
-        atomicAdd(o, a.x); atomicAdd(o + 1, a.y); atomicAdd(o + 2, a.z); atomicAdd(o + 3, a.w);
+    if (SG > 1) {
+        part[sg * 64 + lane] = a;
+        __syncthreads();
+        if (sg == 0) {
+#pragma unroll
+            for (int g = 1; g < SG; ++g) {
+                const float4 v = part[g * 64 + lane];
+                a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+            }
+        }
     }
+    if (sg != 0 || !live) return;
+    const int64_t idx = e4 * 4;
+    const int plane = Cout * Cin;
+    const int tap = (int)(idx / plane);
+    const int rem = (int)(idx - (int64_t)tap * plane);
+    const int co = rem / Cin, ci = rem - co * Cin;  // Cin % 4 == 0: the quad stays in one row
+    if (co >= cout_o) return;
+    const float r[4] = {a.x * gain, a.y * gain, a.z * gain, a.w * gain};
+    float* __restrict__ o = out + ((int64_t)co * cin_o + ci) * taps + tap;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (ci + j < cin_o) o[(int64_t)j * taps] = r[j];
 }
 
 struct TiledPlan {
@@ -349,8 +370,8 @@ int64_t gan_wgrad_tiled_workspace(int N, int Ho, int Wo, int Cin, int Cout, int 
     return (int64_t)pl.S * kh * kw * Cout * Cin;
 }
 
-// 1 = served (dw zeroed by the caller), 0 = not eligible / workspace too small, < 0 = error.
-int gan_conv2d_wgrad_tiled(const void* x, const void* gy, float* dw, const float* in_scale, int N, int H, int W,
+// 1 = served, 0 = not eligible / workspace too small, < 0 = error.
+int gan_conv2d_wgrad_tiled(const void* x, const void* gy, const DwOut& dwo, const float* in_scale, int N, int H, int W,
                            int Cin, int up2, int Ho, int Wo, int Cout, int kh, int kw, int py, int px, float* ws,
                            int64_t ws_floats, const WgradFuse& fu, hipStream_t st) {
     const int64_t need = gan_wgrad_tiled_workspace(N, Ho, Wo, Cin, Cout, kh, kw, py, px);
@@ -389,16 +410,26 @@ int gan_conv2d_wgrad_tiled(const void* x, const void* gy, float* dw, const float
         gan_set_error("conv2d_wgrad(tiled): launch failed: %s", hipGetErrorString(e));
         return GAN_ERR_LAUNCH;
     }
-    const int rc = gan_reduce_slices(ws, dw, (int64_t)kh * kw * Cout * Cin, pl.S, fu.gain, st);
+    const int rc = gan_finalize_dw(ws, pl.S, kh * kw, Cout, Cin, dwo, fu.gain, st);
     return rc == GAN_OK ? 1 : rc;
 }
 
-int gan_reduce_slices(const float* ws, float* out, int64_t L, int S, float gain, hipStream_t st) {
-    const int64_t blocks = ceil_div64(ceil_div64(L, 4), 256);
-    hipLaunchKernelGGL(reduce_slices_k, dim3((unsigned)blocks, (unsigned)((S + 31) / 32)), dim3(256), 0, st, ws, out, L, S, gain);
+int gan_finalize_dw(const float* ws, int S, int taps, int Cout, int Cin, const DwOut& dwo, float gain, hipStream_t st) {
+    const int64_t L = (int64_t)taps * Cout * Cin;
+    if ((Cin & 3) || S < 1 || dwo.cout > Cout || dwo.cin > Cin) {
+        gan_set_error("finalize_dw: bad shape (Cin %d must be a multiple of 4, S %d >= 1)", Cin, S);
+        return GAN_ERR_ARG;
+    }
+    const unsigned blocks = (unsigned)ceil_div64(ceil_div64(L, 4), 64);
+    if (S <= 8)
+        hipLaunchKernelGGL(finalize_dw_k<1>, dim3(blocks), dim3(64), 0, st, ws, dwo.out, L, S, taps, Cout, Cin, dwo.cout, dwo.cin, gain);
+    else if (S <= 64)
+        hipLaunchKernelGGL(finalize_dw_k<4>, dim3(blocks), dim3(256), 0, st, ws, dwo.out, L, S, taps, Cout, Cin, dwo.cout, dwo.cin, gain);
+    else
+        hipLaunchKernelGGL(finalize_dw_k<16>, dim3(blocks), dim3(1024), 0, st, ws, dwo.out, L, S, taps, Cout, Cin, dwo.cout, dwo.cin, gain);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
-        gan_set_error("reduce_slices: launch failed: %s", hipGetErrorString(e));
+        gan_set_error("finalize_dw: launch failed: %s", hipGetErrorString(e));
         return GAN_ERR_LAUNCH;
     }
     return GAN_OK;

@@ -504,9 +504,9 @@ def raw_conv2d_wgrad(
         in_scale = _f32(in_scale).reshape(n, cin)
         if cin_p != cin:
             in_scale = F.pad(in_scale, (0, cin_p - cin)).contiguous()
-    dw = torch.empty((kh * kw, cout_p, cin_p), dtype=torch.float32, device=x.device)
+    dw = torch.empty((cout, cin, kh, kw), dtype=torch.float32, device=x.device)
     # split-K partials go to a caller-owned workspace (the library never allocates); torch's caching
-    # allocator hands the same block back every step
+    # allocator hands the same block back every step.  The slice reducer writes dw in the parameter's layout.
     ws_floats = lib.gan_conv2d_wgrad_workspace(n, h, w, cin_p, int(up2), ho, wo, cout_p, kh, kw, py, px, dtype_code(x))
     ws = torch.empty((ws_floats,), dtype=torch.float32, device=x.device) if ws_floats > 0 else None
     thin_w = (x.dtype == torch.bfloat16 and kh == kw and kh in (1, 3) and py == px == (kh - 1) // 2 and cin_p <= 64
@@ -515,14 +515,14 @@ def raw_conv2d_wgrad(
         _run(
             "conv2d_wgrad_thin" if thin_w else "conv2d_wgrad", 2.0 * n * ho * wo * cout * cin * kh * kw, _nbytes(x, gy, dw),
             lambda: lib.gan_conv2d_wgrad(
-                ptr(x), ptr(gy), ptr(dw), ptr(in_scale), n, h, w, cin_p, int(up2), ho, wo, cout_p, kh, kw, py, px,
+                ptr(x), ptr(gy), ptr(dw), cout, cin, ptr(in_scale), n, h, w, cin_p, int(up2), ho, wo, cout_p, kh, kw, py, px,
                 ptr(ws), ws_floats, float(x_slope), int(pooled), 0.25 if pooled else 1.0, dtype_code(x), stream_of(x)
             ),
             (n, cin, ho, wo, cout, kh, int(up2), int(pooled)),
         ),
         "gan_conv2d_wgrad",
     )
-    return dw[:, :cout, :cin].reshape(kh, kw, cout, cin).permute(2, 3, 0, 1).contiguous()
+    return dw
 
 
 def raw_mbstd_stat(x: Tensor, group: int) -> Tensor:

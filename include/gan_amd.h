@@ -131,13 +131,15 @@ int gan_conv2d_fwd(const void* x, const void* wt, void* y, const float* in_scale
                    float in_slope, int pool, const void* aux, float aux_slope, float gain, const void* resid, int dtype,
                    gan_stream_t stream);
 
-/* Weight gradient (autograd of the convolutions above):
- * dw[tap][co][ci] = sum_{n,oy,ox} gy[n,oy,ox,co] * X[n,oy+dy-py,ox+dx-px,ci] * in_scale[n,ci]
- * dw: fp32 [kh*kw][Cout][Cin], zeroed here.  Cin % 16 == 0 and Cout % 16 == 0 (callers pad).
- * The reduction over pixels is split over workgroups; with a workspace of at least
- * gan_conv2d_wgrad_workspace(...) floats (16-byte aligned, contents undefined on entry and exit) the
- * partial tiles are written with plain stores and folded by a second kernel, otherwise (workspace NULL)
- * they are accumulated into dw with fp32 atomics.  The library never allocates: the caller owns it.
+/* Weight gradient (autograd of the convolutions above; torch.nn.grad.conv2d_weight in the reference's autograd):
+ * dw[co][ci][ky][kx] = gain * sum_{n,oy,ox} gy[n,oy,ox,co] * X[n,oy+ky-py,ox+kx-px,ci] * in_scale[n,ci]
+ * dw: fp32 (Cout_out, Cin_out, kh, kw) contiguous -- the parameter's own layout; every element is written
+ * (no need to zero it).  x / gy carry Cin / Cout channels, multiples of 16 (callers pad with zeros);
+ * Cout_out <= Cout and Cin_out <= Cin are the un-padded counts.
+ * The reduction over pixels is split over workgroups: partial tiles go to `workspace` (at least
+ * gan_conv2d_wgrad_workspace(...) floats, 16-byte aligned, contents undefined on entry and exit) with plain
+ * stores -- or, on the register-staged fallback kernel, with fp32 atomics into one zeroed slice of it -- and a
+ * second kernel folds them into dw.  The library never allocates: the caller owns the workspace.
  * Fused stages (the weight gradient of the LeakyReLU -> Conv2d -> AvgPool2d chain, progressive_gan.py:45-50):
  *   x_slope != 1 : X = leaky_relu(x, x_slope) as it is staged (before in_scale);
  *   gy_up2 = 1   : gy is [N][Ho/2][Wo/2][Cout] and read through a nearest-neighbour 2x gather (the adjoint
@@ -145,7 +147,7 @@ int gan_conv2d_fwd(const void* x, const void* wt, void* y, const float* in_scale
  *   gain         : scalar factor on dw.  Pass 1, 0, 1 for none. */
 int64_t gan_conv2d_wgrad_workspace(int N, int H, int W, int Cin, int up2, int Ho, int Wo, int Cout, int kh, int kw,
                                    int py, int px, int dtype);
-int gan_conv2d_wgrad(const void* x, const void* gy, float* dw, const float* in_scale, int N, int H, int W, int Cin,
+int gan_conv2d_wgrad(const void* x, const void* gy, float* dw, int Cout_out, int Cin_out, const float* in_scale, int N, int H, int W, int Cin,
                      int up2, int Ho, int Wo, int Cout, int kh, int kw, int py, int px, float* workspace,
                      int64_t workspace_floats, float x_slope, int gy_up2, float gain, int dtype, gan_stream_t stream);
 
