@@ -350,6 +350,56 @@ int launch(const ConvArgs& a, hipStream_t st) {
 
 }  // namespace
 
+// ---- full-window convolution with a handful of output channels -----------------------------------
+// kh == H, kw == W, no padding: one output pixel per image (the discriminator's last layer, 4x4x512 -> 1,
+// progressive_gan.py:76).  As an implicit GEMM it is 256 x 1 x 8192: a tile kernel runs it in one or two
+// workgroups that walk K serially (243 us at batch 256).  Here a workgroup owns one image and its lanes split K:
+// y[n][co] = act(gain * sum_k lrelu_in(x[n][k]) * wt[co][k] + bias[co]); x's NHWC order IS the k order.
+template <typename T>
+__global__ void __launch_bounds__(256) conv_full_k(const T* __restrict__ x, const T* __restrict__ wt, T* __restrict__ y,
+                                                   const float* __restrict__ bias, int K, int Kpad, int Cout, float in_slope,
+                                                   float gain, float slope) {
+    constexpr int V = 16 / sizeof(T);
+    __shared__ float red[4][8];
+    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const T* __restrict__ xr = x + (int64_t)n * K;
+    float acc[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) acc[c] = 0.f;
+    for (int k = tid * V; k < K; k += 256 * V) {  // K % V == 0 (Cin % 8 == 0)
+        const uint4 xv = *reinterpret_cast<const uint4*>(xr + k);
+        const T* xe = reinterpret_cast<const T*>(&xv);
+        float xf[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            const float v = (float)xe[j];
+            xf[j] = v > 0.f ? v : v * in_slope;
+        }
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            if (c < Cout) {
+                const uint4 wv = *reinterpret_cast<const uint4*>(wt + (int64_t)c * Kpad + k);
+                const T* we = reinterpret_cast<const T*>(&wv);
+#pragma unroll
+                for (int j = 0; j < V; ++j) acc[c] += xf[j] * (float)we[j];
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc[c] += __shfl_xor(acc[c], o);
+        if (lane == 0) red[wave][c] = acc[c];
+    }
+    __syncthreads();
+    if (tid < Cout) {
+        float v = (red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid]) * gain;
+        if (bias) v += bias[tid];
+        v = v > 0.f ? v : v * slope;
+        y[(int64_t)n * Cout + tid] = (T)v;
+    }
+}
+
 extern "C" int gan_conv2d_fwd(const void* x, const void* wt, void* y, const float* in_scale, const float* out_scale,
                               const float* bias, const void* noise, const float* noise_scale, float slope, int N,
                               int H, int W, int Cin, int up2, int Ho, int Wo, int Cout, int kh, int kw, int py, int px,
@@ -382,6 +432,17 @@ extern "C" int gan_conv2d_fwd(const void* x, const void* wt, void* y, const floa
     a.ksteps = (kh * kw * Cin + 31) / 32;
     a.M = (int64_t)N * Ho * Wo;
     hipStream_t st = (hipStream_t)stream;
+    if (Ho == 1 && Wo == 1 && py == 0 && px == 0 && !up2 && Cout <= 8 && !in_scale && !out_scale && !noise && !pool && !aux && !resid) {
+        const int K = H * W * Cin;
+        if (dtype == GAN_F32)
+            hipLaunchKernelGGL(conv_full_k<float>, dim3((unsigned)N), dim3(256), 0, st, (const float*)x, (const float*)wt, (float*)y, bias,
+                               K, Kpad, Cout, in_slope, gain, slope);
+        else
+            hipLaunchKernelGGL(conv_full_k<bf16>, dim3((unsigned)N), dim3(256), 0, st, (const bf16*)x, (const bf16*)wt, (bf16*)y, bias, K,
+                               Kpad, Cout, in_slope, gain, slope);
+        GAN_CHECK_LAUNCH("conv2d_fwd(full window)");
+        return GAN_OK;
+    }
     if (dtype == GAN_F32) return launch<float>(a, st);
     // thin layers (Cin, Cout <= 64 at >= 32 pixels wide) are HBM-bound: halo-tiled direct kernel
     const int thin = gan_conv2d_fwd_thin(x, wt, y, in_scale, out_scale, bias, noise, noise_scale, slope, N, H, W, Cin,

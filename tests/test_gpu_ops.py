@@ -614,3 +614,33 @@ def test_pad_channels_kernel(dev, in_dtype, out_dtype):
         assert out.is_contiguous(memory_format=torch.channels_last)
         assert torch.equal(out, ref)
         assert GF._pad_channels(x, 16, out_dtype) is out  # memo: the weight gradient pads the same tensor
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", [(7, 512, 4, 4, 1), (3, 40, 5, 3, 3), (2, 513, 4, 4, 8), (260, 64, 2, 2, 2)])
+def test_conv2d_full_window_kernel(dev, case, dtype):
+    """Kernel == input, no padding (the discriminator's last layer, progressive_gan.py:76): the per-image
+    dot-product kernel, with bias / activations, and its gradients through Conv2dFn."""
+    import gan_amd.functional as GF
+
+    n, cin, h, w, cout = case
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wgt = torch.randn(cout, cin, h, w, generator=g) / (cin * h * w) ** 0.5
+    b = torch.randn(cout, generator=g)
+    tol = TOL32 if dtype == torch.float32 else TOLBF
+    xd = x.to(dev).to(dtype).contiguous(memory_format=torch.channels_last)
+    xr, wr = xd.double().cpu(), (wgt.to(dev).to(dtype) if dtype == torch.bfloat16 else wgt).double().cpu()
+    y = GF.raw_conv2d(xd, wgt.to(dev), 0, 0, bias=b.to(dev), slope=0.2, in_slope=0.2, gain=0.5)
+    ref = F.leaky_relu(0.5 * F.conv2d(F.leaky_relu(xr, 0.2), wr) + b.double().view(1, -1, 1, 1), 0.2)
+    assert y.shape == (n, cout, 1, 1)
+    assert rel_err(y, ref) < tol
+    xg = xd.clone().requires_grad_(True)
+    wg = wgt.to(dev).requires_grad_(True)
+    out = GF.Conv2dFn.apply(xg, wg, 0, 0)
+    gx, gw = torch.autograd.grad(out.float().square().sum(), (xg, wg))
+    xr2, wr2 = xr.clone().requires_grad_(True), wr.clone().requires_grad_(True)
+    o2 = F.conv2d(xr2, wr2)
+    gx2, gw2 = torch.autograd.grad(o2.square().sum(), (xr2, wr2))
+    assert rel_err(out, o2) < tol
+    assert rel_err(gx, gx2) < 2 * tol and rel_err(gw, gw2) < 2 * tol
