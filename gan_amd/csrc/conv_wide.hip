@@ -21,6 +21,7 @@
 // apply them in a pass of their own for these layers (the tensors are small: <= 134 MB at batch 256), or the
 // register-staged kernel in conv_fwd.hip takes the call.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -64,7 +65,7 @@ struct WideCursor {
 };
 
 // LDS-DMA of one K step (64 channels of one tap) into stage `buf`, then advance the cursor
-template <int BN>
+template <int BN, int NST>
 __device__ __forceinline__ void wide_issue(WideCursor& cur, char* lds, int buf, int wave, __amdgpu_buffer_rsrc_t rx,
                                            __amdgpu_buffer_rsrc_t rw, const unsigned (&b_off)[BN / 32], const int (&a_n)[4],
                                            const int (&a_yx)[4], int csrc, const WideArgs& p) {
@@ -92,12 +93,18 @@ __device__ __forceinline__ void wide_issue(WideCursor& cur, char* lds, int buf, 
     }
 }
 
-template <int BN>
-__global__ void __launch_bounds__(256, 2) conv_wide_k(const WideArgs p) {
+// NST = 2: two stages, two workgroups per CU -- the shape for grids that fill the chip, where the L2 -> LDS
+// stream (not its latency) bounds a step.  NST = 4: small grids (small maps / per-GPU batches: fewer tiles than
+// CUs) are bound by the DMA round trip of every step instead (0.76 us per step at 512 channels on 8x8, batch
+// 32); three steps in flight hide it.  One barrier per step either way.
+template <int BN, int NST>
+__global__ void __launch_bounds__(256, NST == 2 ? 2 : 1) conv_wide_k(const WideArgs p) {
     constexpr int BM = 128, FP = 4, FC = BN / 32;          // wave tile: 64 pixels x BN/2 channels
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;  // one stage: pixel tile, weight tile (64 k each)
     constexpr int STAGE = A_BYTES + B_BYTES;
-    __shared__ __attribute__((aligned(1024))) char lds[2 * STAGE];
+    constexpr int PER = 4 + BN / 32;                       // LDS-DMA instructions per wave and step
+    extern __shared__ __attribute__((aligned(1024))) char lds_raw[];
+    char* const lds = lds_raw;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -161,13 +168,24 @@ __global__ void __launch_bounds__(256, 2) conv_wide_k(const WideArgs p) {
     const int sw0 = ((fq) ^ (frow >> 1)) << 4, sw1 = ((4 + fq) ^ (frow >> 1)) << 4;
     const int xrow = (wm * 64 + frow) * 128, wrow = (wn * (BN / 2) + frow) * 128;
 
-    wide_issue<BN>(cur, lds, 0, wave, rx, rw, b_off, a_n, a_yx, csrc, p);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NST - 1; ++i)
+        if (i < p.ksteps) wide_issue<BN, NST>(cur, lds, i, wave, rx, rw, b_off, a_n, a_yx, csrc, p);
 
     for (int s = 0; s < p.ksteps; ++s) {
-        const int buf = s & 1;
-        if (s + 1 < p.ksteps) wide_issue<BN>(cur, lds, buf ^ 1, wave, rx, rw, b_off, a_n, a_yx, csrc, p);
+        // this wave's share of step s has landed: all but the (NST - 2) younger steps' DMAs are done (in the
+        // tail fewer are in flight, so wait for everything)
+        if (NST > 2 && s + NST - 2 < p.ksteps) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * PER) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        // ... everyone's share, and everyone is done reading the stage of step s - 1.  A bare s_barrier:
+        // __syncthreads() carries a fence that drains vmcnt to 0, i.e. the younger steps' DMAs with it.
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const int buf = s % NST;
+        if (s + NST - 1 < p.ksteps) wide_issue<BN, NST>(cur, lds, (s + NST - 1) % NST, wave, rx, rw, b_off, a_n, a_yx, csrc, p);
         const char* const A = lds + buf * STAGE;
         const char* const B = A + A_BYTES;
 #pragma unroll
@@ -183,8 +201,6 @@ __global__ void __launch_bounds__(256, 2) conv_wide_k(const WideArgs p) {
 #pragma unroll
                 for (int f = 0; f < FP; ++f) acc[i][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[f], acc[i][f], 0, 0, 0);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next stage has landed (this wave's share)
-        __syncthreads();                                  // ... everyone's, and everyone is done reading this one
     }
 
     // ---- epilogue: lane holds channels co0..co0+3 (co0 = bn0 + wn*BN/2 + 16*i + 4*fq) of pixel row f*16 + frow
@@ -280,12 +296,17 @@ int gan_conv2d_fwd_wide(const void* x, const void* wt, void* y, const float* out
     a.pool = fu.pool; a.M = (int)M;
     a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb; a.y_bytes = (unsigned)yb;
     const unsigned gm = (unsigned)((M + 127) / 128);
-    if (Cout > 64) {
-        const unsigned gn = (unsigned)((Cout + 127) / 128);
-        if (gn > 65535) return 0;
-        hipLaunchKernelGGL(conv_wide_k<128>, dim3(gm, gn), dim3(256), 0, st, a);
+    const unsigned gn = (unsigned)((Cout + 127) / 128), gn64 = (unsigned)((Cout + 63) / 64);
+    if (gn64 > 65535) return 0;
+    static const int thr = getenv("GAN_AMD_WIDE_THR") ? atoi(getenv("GAN_AMD_WIDE_THR")) : 256;
+    // 128 x 128 tiles when they fill the chip (two workgroups per CU); small maps / batches get 128 x 64 tiles
+    // and a four-stage ring (conv_wide_k's header)
+    if (Cout > 64 && (int64_t)gm * gn >= thr) {
+        hipLaunchKernelGGL((conv_wide_k<128, 2>), dim3(gm, gn), dim3(256), 2 * (128 + 128) * 128, st, a);
+    } else if ((int64_t)gm * gn64 >= 2 * thr) {
+        hipLaunchKernelGGL((conv_wide_k<64, 2>), dim3(gm, gn64), dim3(256), 2 * (128 + 64) * 128, st, a);
     } else {
-        hipLaunchKernelGGL(conv_wide_k<64>, dim3(gm, 1), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((conv_wide_k<64, 4>), dim3(gm, gn64), dim3(256), 4 * (128 + 64) * 128, st, a);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
