@@ -1,7 +1,8 @@
-"""Python call sites of the aten ops on image-sized tensors in one iteration (profiling aid): python tools/op_stack.py"""
+"""Python call sites of the small aten ops in one iteration (profiling aid): python tools/op_stack.py [op ...]"""
 import sys, collections, torch
 sys.path.insert(0, '.')
-sys.argv = ['bench.py', '--no_graph']
+ops = set(sys.argv[1:]) or {"aten::copy_", "aten::add_", "aten::add", "aten::sum", "aten::fill_", "aten::zero_", "aten::mul"}
+sys.argv = ['bench.py', '--no_graph', '--global_batch', '32']
 import bench
 from gan_amd.train_celeba import synthetic_reals
 from torch.profiler import profile, ProfilerActivity
@@ -14,18 +15,17 @@ for _ in range(2):
     tr.train_step(nxt)
 torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
-    tr.train_step(nxt)
+    for red in tr._iteration(nxt, overlap=False):  # the op sequence the HIP graphs capture
+        tr._flat_allreduce(red)
     torch.cuda.synchronize()
-agg = collections.defaultdict(lambda: [0, 0.0])
-for ev in prof.events():
-    if ev.device_type != torch.autograd.DeviceType.CPU or not ev.name.startswith('aten::') or not ev.kernels:
+agg = collections.Counter()
+tot = collections.Counter()
+for ev in prof.key_averages(group_by_input_shape=True):
+    if not ev.key.startswith('aten::') or ev.device_time_total <= 0:
         continue
-    kt = sum(k.duration for k in ev.kernels)
-    if kt < 20:
-        continue
-    st = [s for s in (ev.stack or []) if 'gan_amd' in s or 'bench.py' in s][:3]
-    key = (ev.name, str(ev.input_shapes)[:60], ' <- '.join(s.split('/')[-1][:60] for s in st))
-    agg[key][0] += 1
-    agg[key][1] += kt
-for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
-    print(f"{v[0]:3d} {v[1]/1e3:7.3f} ms {k[0]:16s} {k[1]:60s} {k[2]}")
+    tot[ev.key] += ev.count
+    if ev.key in ops:
+        agg[(ev.key, str(ev.input_shapes)[:100])] += ev.count
+print(tot.most_common(40))
+for k, v in agg.most_common(70):
+    print(f"{v:4d} {k[0]:14s} {k[1]}")
