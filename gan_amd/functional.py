@@ -222,16 +222,20 @@ def raw_chan_dot(A: Tensor, B: Optional[Tensor], b_mode: int, ymask: Optional[Te
     # Always reduce per sample in the kernel: N x fewer workgroups add into one address (a batch-wide sum
     # straight from the kernel is bound by fp32-atomic contention, 0.08-0.17 TB/s measured); the (N, C)
     # partials are folded over N by one tiny reduction.
-    out = torch.empty((n, c), dtype=torch.float32, device=A.device)
+    # partials are folded over N by one tiny reduction.  Small tensors (the wide layers' 4x4 .. 16x16 maps) add
+    # straight into (C,): there the extra launch costs more than the contention.
+    direct = not per_sample and A.numel() <= (1 << 21)
+    out = torch.empty((c,) if direct else (n, c), dtype=torch.float32, device=A.device)
     check(
         _run(
             "chan_dot", 0, _nbytes(A, B, ymask),
-            lambda: lib.gan_chan_dot(ptr(A), ptr(B), b_mode, ptr(ymask), float(slope), ptr(out), c, n, h * w, c, dtype_code(A), stream_of(A)),
+            lambda: lib.gan_chan_dot(ptr(A), ptr(B), b_mode, ptr(ymask), float(slope), ptr(out), 0 if direct else c, n, h * w, c,
+                                     dtype_code(A), stream_of(A)),
             (n, c, h, w, b_mode, int(ymask is not None), int(per_sample)),
         ),
         "gan_chan_dot",
     )
-    return out if per_sample else out.sum(0)
+    return out if (per_sample or direct) else out.sum(0)
 
 
 def raw_modconv_bwd_pre(gy: Tensor, y: Optional[Tensor], noise: Optional[Tensor], dinv: Optional[Tensor], slope: float):
@@ -259,6 +263,21 @@ def raw_modconv_bwd_pre(gy: Tensor, y: Optional[Tensor], noise: Optional[Tensor]
         "gan_modconv_bwd_pre",
     )
     return gz, sums
+
+
+def raw_modconv_bwd_post(sums: Tensor, bias: Optional[Tensor], ns: Optional[Tensor], dinv: Optional[Tensor],
+                         want_gb: bool, want_gns: bool, want_gdinv: bool):
+    """(gb (C,), gns (C,), gdinv (N, C)) in fp32 from raw_modconv_bwd_pre's sums (N, 3, C); None where not wanted."""
+    require_gpu(sums, bias, ns, dinv)
+    lib = _lib.load()
+    n, _, c = sums.shape
+    b32, s32, d32 = _f32(bias), _f32(ns), _f32(dinv)
+    gb = torch.empty((c,), dtype=torch.float32, device=sums.device) if want_gb else None
+    gns = torch.empty((c,), dtype=torch.float32, device=sums.device) if want_gns else None
+    gdinv = torch.empty((n, c), dtype=torch.float32, device=sums.device) if want_gdinv else None
+    check(lib.gan_modconv_bwd_post(ptr(sums), ptr(b32), ptr(s32), ptr(d32), ptr(gb), ptr(gns), ptr(gdinv), n, c, stream_of(sums)),
+          "gan_modconv_bwd_post")
+    return gb, gns, gdinv
 
 
 def raw_scale_dot(A: Tensor, B: Tensor, a: Tensor):

@@ -67,19 +67,18 @@ class ModConvFn(Function):
         gz, sums = GF.raw_modconv_bwd_pre(gy, y if slope != 1.0 else None, noise if ns is not None else None, dinv, slope)
         if slope == 1.0 and dinv is not None and need[3]:  # no activation: the kernel had no y to form sum gy*y with
             sums[:, 2] = GF.raw_chan_dot(gy, y, 1, None, 1.0, True)
-        t1, t2 = sums[:, 0], sums[:, 1]
-        if bias is not None and need[4]:
-            gb = t1.sum(0).reshape(bias.shape).to(bias.dtype)
-        if ns is not None and need[6]:
-            gns = t2.sum(0).reshape(ns.shape).to(ns.dtype)
-        if dinv is not None and need[3]:
+        want_gb = bias is not None and need[4]
+        want_gns = ns is not None and need[6]
+        want_gdinv = dinv is not None and need[3]
+        if want_gb or want_gns or want_gdinv:
             # z*dinv = lrelu^-1(y) - b - noise*ns   and   gy*m(y)*lrelu^-1(y) = gy*y
-            acc = sums[:, 2]
-            if bias is not None:
-                acc = acc - t1 * bias.detach().float().reshape(1, -1)
-            if ns is not None:
-                acc = acc - t2 * ns.detach().float().reshape(1, -1)
-            gdinv = (acc / dinv.detach().float()).reshape(dinv.shape).to(dinv.dtype)
+            gb, gns, gdinv = GF.raw_modconv_bwd_post(sums, bias, ns if ns is not None else None, dinv, want_gb, want_gns, want_gdinv)
+            if gb is not None:
+                gb = gb.reshape(bias.shape).to(bias.dtype)
+            if gns is not None:
+                gns = gns.reshape(ns.shape).to(ns.dtype)
+            if gdinv is not None:
+                gdinv = gdinv.reshape(dinv.shape).to(dinv.dtype)
         gx = gw = gs = None
         if need[0] or need[2]:
             # d/d(U(x)*s); with U = nearest x2 its adjoint (the sum of each 2x2 block) rides on the accumulators

@@ -85,11 +85,17 @@ int gan_chan_dot(const void* A, const void* B, int b_mode, const void* ymask, fl
  *   gan_modconv_bwd_pre: gz = gy * m(y) * dinv[n,c]                     (y, noise, dinv may be NULL)
  *        sums[n][0][c] = sum_hw gy*m(y), sums[n][1][c] = sum_hw gy*m(y)*noise[n,hw], sums[n][2][c] = sum_hw gy*y
  *        sums: fp32 [N][3][C], zeroed here (rows 1 / 2 stay zero without noise / y).
- *   gan_scale_dot:       out = A * a[n,c],  dot[n][c] = sum_hw A*B       (dot: fp32 [N][C], zeroed here). */
+ *   gan_scale_dot:       out = A * a[n,c],  dot[n][c] = sum_hw A*B       (dot: fp32 [N][C], zeroed here).
+ *   gan_modconv_bwd_post: the parameter gradients from `sums` in one launch (any output may be NULL):
+ *        gb[c] = sum_n sums[n][0][c],  gns[c] = sum_n sums[n][1][c],
+ *        gdinv[n][c] = (sums[n][2][c] - sums[n][0][c]*bias[c] - sums[n][1][c]*ns[c]) / dinv[n][c]
+ *        (bias / ns NULL = 0; all fp32). */
 int gan_modconv_bwd_pre(const void* gy, const void* y, const void* noise, const float* dinv, float slope, void* gz,
                         float* sums, int N, int64_t HW, int C, int dtype, gan_stream_t stream);
 int gan_scale_dot(const void* A, const void* B, const float* a, void* out, float* dot, int N, int64_t HW, int C, int dtype,
                   gan_stream_t stream);
+int gan_modconv_bwd_post(const float* sums, const float* bias, const float* ns, const float* dinv, float* gb, float* gns,
+                         float* gdinv, int N, int C, gan_stream_t stream);
 
 /* Demodulation factor of ModulatedConv2d: replaces F.normalize(weight * s, dim=(2,3,4), eps=1e-8)
  * (modelling/stylegan2.py:33) by dinv[n][co] = 1 / max(sqrt(sum_ci s[n,ci]^2 * wsq[co,ci]), 1e-8),
