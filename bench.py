@@ -49,6 +49,8 @@ def parse():
     ap.add_argument("--global_batch", type=int, default=256)
     ap.add_argument("--micro_batch", type=int, default=256, help="largest per-rank batch per backward pass (grad_accum above it)")
     ap.add_argument("--base_dim", type=int, default=16)
+    ap.add_argument("--recipe", choices=["stylegan2", "dcgan"], default="stylegan2",
+                    help="stylegan2: hinge+R1 (BASELINE configs 3/4); dcgan: DCGAN WGAN-GP n_disc=5 at 64x64 (config 5, README.md:55)")
     ap.add_argument("--fp32", action="store_true", help="fp32 instead of bf16 autocast (debug)")
     ap.add_argument("--no_cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no_micro", action="store_true", help="skip the upfirdn2d microbenchmark leg")
@@ -65,12 +67,19 @@ def make_trainer(args, device, world):
     # grad_accum (train_celeba.py:38,120): smallest split whose micro-batch fits --micro_batch and keeps
     # whole MinibatchStdDev groups of 4
     accum = next(a for a in range(1, local + 1) if local % a == 0 and local // a <= args.micro_batch and (local // a) % 4 == 0)
-    cfg = TrainConfig(
-        model="stylegan2", img_size=args.img_size, gen_kwargs={"base_dim": args.base_dim}, disc_kwargs={"base_dim": args.base_dim},
-        method="hinge", regularizer="r1", batch_size=args.global_batch, optimizer="Adam", optimizer_kwargs={"betas": [0.0, 0.9]},
-        lr=2e-4, device="cuda", mixed_precision=not args.fp32, channels_last=True, grad_accum=accum,
-        hip_graph=not args.no_graph, graph_warmup=1,
-    )
+    if args.recipe == "dcgan":
+        cfg = TrainConfig(
+            model="dcgan", img_size=args.img_size, gen_kwargs={}, disc_kwargs={"norm": "none"}, method="wgan", regularizer="wgan-gp",
+            n_disc=5, batch_size=args.global_batch, optimizer="Adam", optimizer_kwargs={"betas": [0.0, 0.9]}, lr=1e-4, device="cuda",
+            mixed_precision=not args.fp32, channels_last=True, grad_accum=accum, hip_graph=not args.no_graph, graph_warmup=1,
+        )
+    else:
+        cfg = TrainConfig(
+            model="stylegan2", img_size=args.img_size, gen_kwargs={"base_dim": args.base_dim}, disc_kwargs={"base_dim": args.base_dim},
+            method="hinge", regularizer="r1", batch_size=args.global_batch, optimizer="Adam", optimizer_kwargs={"betas": [0.0, 0.9]},
+            lr=2e-4, device="cuda", mixed_precision=not args.fp32, channels_last=True, grad_accum=accum,
+            hip_graph=not args.no_graph, graph_warmup=1,
+        )
     return cfg, Trainer(cfg, device, world), local // accum
 
 
@@ -256,7 +265,8 @@ def main():
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         line = {
-            "metric": "StyleGAN2 G+D+R1 train img/s @256x256" if args.img_size == 256 else f"StyleGAN2 G+D+R1 train img/s @{args.img_size}",
+            "metric": (f"DCGAN WGAN-GP n_disc=5 train img/s @{args.img_size}" if args.recipe == "dcgan" else
+                       "StyleGAN2 G+D+R1 train img/s @256x256" if args.img_size == 256 else f"StyleGAN2 G+D+R1 train img/s @{args.img_size}"),
             "value": round(args.global_batch * args.steps / elapsed, 2),
             "unit": "img/s",
             "n_gpus": world,
@@ -269,7 +279,9 @@ def main():
             "dtype": "fp32" if args.fp32 else "bf16",
             "data": "synthetic",
             "config": {
-                "workload": f"StyleGAN2 hinge+R1 train step, {args.img_size}x{args.img_size}, base_dim {args.base_dim}, global batch {args.global_batch}, Adam, EMA",
+                "workload": (f"DCGAN WGAN-GP n_disc=5 train iteration, {args.img_size}x{args.img_size}, global batch {args.global_batch}, Adam, EMA"
+                             if args.recipe == "dcgan" else
+                             f"StyleGAN2 hinge+R1 train step, {args.img_size}x{args.img_size}, base_dim {args.base_dim}, global batch {args.global_batch}, Adam, EMA"),
                 "global_batch": args.global_batch,
                 "per_gpu_batch": args.global_batch // world,
                 "grad_accum": cfg.grad_accum,
