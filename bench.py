@@ -35,7 +35,7 @@ import torch.distributed as dist  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16
 # profile family (gan_amd/functional.py) -> device kernel; the first three are priced against the MFMA peak
-MFMA_FAMILIES = {"conv2d_fwd_wide128": "conv_wide_k<128>", "conv2d_fwd_wide64": "conv_wide_k<64>",
+MFMA_FAMILIES = {"conv2d_fwd_wide128": "conv_wide_k<128, 2>", "conv2d_fwd_wide64": "conv_wide_k<64, 2> / conv_wide_k<64, 4>",
                  "conv2d_fwd": "conv_fwd_k<...>", "conv2d_wgrad": "conv_wgrad_tiled_k<...> / conv_wgrad_k<...>"}
 HBM_FAMILIES = {"conv2d_fwd_thin": "conv_thin_k<...>", "conv2d_wgrad_thin": "conv_thin_wgrad_k<...>"}
 

@@ -41,7 +41,10 @@ __device__ __forceinline__ bf16x8 fir_tr_frag(const char* p) {
 
 __global__ void __launch_bounds__(256, 4) upfirdn2d_mfma_k(const FirArgs p) {
     extern __shared__ __attribute__((aligned(256))) char fir_lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    // wave-uniform by construction: as an SGPR the row / region arithmetic below runs on the scalar unit
+    // (PMC: 750 VALU instructions per wave and tile against 48 MFMAs, most of them uniform address math)
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
     const int up = 1 << p.up_log2, down = p.down;
     const int ncg = 1 << p.ncg_log2;
@@ -90,17 +93,18 @@ __global__ void __launch_bounds__(256, 4) upfirdn2d_mfma_k(const FirArgs p) {
         const int iy1 = ((oy0 + p.TH - 1) * down - p.py1 + p.ky - 1) >> p.up_log2;
         const int npix = (iy1 - iy0 + 1) * p.RWr;
         const int nchunk = ((npix + 7) >> 3) * 8 * CP;
-        const bf16* __restrict__ xb = p.x + (int64_t)cb * ncg * 16;
+        // uniform 64-bit base of the region's first pixel, 32-bit per-lane offsets from it
+        const bf16* __restrict__ xb = p.x + (((int64_t)n * p.H + iy0) * p.W + ix0) * p.C + (int64_t)cb * ncg * 16;
+        const int sh = p.ncg_log2 + 4;  // 8 * CP chunks per group of 8 pixels
         for (int idx = tid; idx < nchunk; idx += 256) {
-            const int p8 = idx / (8 * CP), r8 = idx - p8 * 8 * CP;
+            const int p8 = idx >> sh, r8 = idx & ((1 << sh) - 1);
             const int c8 = r8 >> 3;
             const int pix = p8 * 8 + (r8 & 7);
             if (pix >= npix) continue;
             const int ry = (int)__umulhi((unsigned)pix, p.rw_magic), rx = pix - ry * p.RWr;  // pix / RWr, exact for pix < 2^16
-            const int iy = iy0 + ry, ix = ix0 + rx;
             uint4 v = make_uint4(0, 0, 0, 0);
-            if (rx < p.ncols && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
-                v = *reinterpret_cast<const uint4*>(xb + (((int64_t)n * p.H + iy) * p.W + ix) * p.C + c8 * 8);
+            if (rx < p.ncols && (unsigned)(iy0 + ry) < (unsigned)p.H && (unsigned)(ix0 + rx) < (unsigned)p.W)
+                v = *reinterpret_cast<const uint4*>(xb + ((ry * p.W + rx) * p.C + c8 * 8));
             *reinterpret_cast<uint4*>(reg + (c8 >> 1) * PL + pix * 32 + (c8 & 1) * 16) = v;
         }
     };

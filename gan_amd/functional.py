@@ -472,7 +472,10 @@ def raw_conv2d(
         mode = "G" if (in_scale is not None or out_scale is not None or noise is not None) else ("DP" if pool else ("DA" if aux is not None else "D"))
         family = f"conv2d_fwd_thin<{cin_p},{16 if cout <= 16 else (32 if cout <= 32 else 64)},{kh},{mode}>"
     elif in_scale is None and in_slope == 1.0 and _wide_kernel_shape(x, cin_p, cout, ho, wo, kh, kw, py, px):
-        family = "conv2d_fwd_wide128" if cout > 64 else "conv2d_fwd_wide64"  # MFMA-bound: conv_wide_k<128> / <64>
+        # MFMA-bound: conv_wide_k<128, 2> when its 128 x 128 tiles fill the chip, else conv_wide_k<64, 2 | 4>
+        # (mirror of the launch selection in conv_wide.hip)
+        big = cout > 64 and ((n * ho * wo + 127) // 128) * ((cout + 127) // 128) >= 256
+        family = "conv2d_fwd_wide128" if big else "conv2d_fwd_wide64"
     else:
         family = "conv2d_fwd"
     check(
