@@ -26,7 +26,7 @@ struct ThinWArgs {
     const float* in_scale;
     int N, H, W, Hl, Wl, up2, Ho, Wo, Cin, Cout, py, px;
     int tiles_x, tiles_y;
-    float* ws;  // optional [gridDim.x * WR][taps][Cout][Cin] partial slices (plain stores) instead of atomics
+    float* ws;  // [gridDim.x][taps][Cout][Cin] partial slices (plain stores), folded by finalize_dw_k
     unsigned x_bytes, g_bytes;  // < 2^31: 32-bit buffer offsets
     WgradFuse fu;
     DwOut dwo;  // host side only: where the slice reducer writes
@@ -214,31 +214,57 @@ __global__ void __launch_bounds__(256, 2) conv_thin_wgrad_k(const ThinWArgs p) {
     }
 
     // ---- flush: D layout col = lane & 15 -> ci, row = 4*(lane >> 4) + r -> co ----------------------
-    // With a workspace every (workgroup, row group) writes its partial sums with plain stores into its own
-    // slice (reduce_slices_k folds them); without one, one fp32 atomic per element into dw.
+    // The WR row groups of the workgroup hold partial sums of the same taps: they are folded through LDS
+    // first (wave wr*WT + wt into wave wt), so a workgroup writes ONE slice of dw with plain stores and the
+    // slice reducer reads WR times fewer of them (it was the larger share of this kernel's traffic on the
+    // 32..64-channel layers).  Gain: in the slice reducer.
     if (t0 < t1) {
-        const int64_t L = (int64_t)KS * KS * p.Cout * p.Cin;
-        float* __restrict__ base = p.ws ? p.ws + ((int64_t)blockIdx.x * C::WR + wr) * L : p.dw;
+        if (C::WR > 1) {
+            static_assert(NT * CGO * CGI * 1024 <= C::LDS_BYTES + 256 * 16, "partial sums of one wave do not fit the tile's LDS");
+            f32x4* const red = reinterpret_cast<f32x4*>(lds);
+            for (int src = WT; src < 4; ++src) {
+                __syncthreads();  // the tile images / the previous round's partials are no longer read
+                if (wave == src) {
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const int tap = wt + j * WT;
-            if (tap >= KS * KS) continue;
-            float* __restrict__ dwt = base + (int64_t)tap * p.Cout * p.Cin;
+                    for (int j = 0; j < NT; ++j)
 #pragma unroll
-            for (int o = 0; o < CGO; ++o)
+                        for (int o = 0; o < CGO; ++o)
 #pragma unroll
-                for (int i = 0; i < CGI; ++i)
+                            for (int i = 0; i < CGI; ++i) red[((j * CGO + o) * CGI + i) * 64 + lane] = acc[j][o][i];
+                }
+                __syncthreads();
+                if (wave == src % WT) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int co = o * 16 + g * 4 + r;
-                        const int ci = i * 16 + li;
-                        if (co < p.Cout && ci < p.Cin) {
-                            if (p.ws)
-                                dwt[(int64_t)co * p.Cin + ci] = acc[j][o][i][r];  // gain: in the slice reducer
-                            else
-                                atomicAdd(dwt + (int64_t)co * p.Cin + ci, acc[j][o][i][r] * p.fu.gain);
+                    for (int j = 0; j < NT; ++j)
+#pragma unroll
+                        for (int o = 0; o < CGO; ++o)
+#pragma unroll
+                            for (int i = 0; i < CGI; ++i) {
+                                const f32x4 v = red[((j * CGO + o) * CGI + i) * 64 + lane];
+                                acc[j][o][i][0] += v[0]; acc[j][o][i][1] += v[1]; acc[j][o][i][2] += v[2]; acc[j][o][i][3] += v[3];
+                            }
+                }
+            }
+        }
+        if (wr == 0) {
+            const int64_t L = (int64_t)KS * KS * p.Cout * p.Cin;
+            float* __restrict__ base = p.ws + (int64_t)blockIdx.x * L;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int tap = wt + j * WT;
+                if (tap >= KS * KS) continue;
+                float* __restrict__ dwt = base + (int64_t)tap * p.Cout * p.Cin;
+#pragma unroll
+                for (int o = 0; o < CGO; ++o)
+#pragma unroll
+                    for (int i = 0; i < CGI; ++i)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int co = o * 16 + g * 4 + r;
+                            const int ci = i * 16 + li;
+                            if (co < p.Cout && ci < p.Cin) dwt[(int64_t)co * p.Cin + ci] = acc[j][o][i][r];
                         }
-                    }
+            }
         }
     }
 }
@@ -261,7 +287,7 @@ int launch_thin_w(ThinWArgs a, int64_t ws_floats, int64_t* need, hipStream_t st)
     int64_t grid = 256LL * per_cu;
     if (grid > ntiles) grid = ntiles;
     const int64_t L = (int64_t)KS * KS * a.Cout * a.Cin;
-    const int64_t want = grid * C::WR * L;
+    const int64_t want = grid * L;
     if (need) {
         *need = want;
         return GAN_OK;
@@ -269,7 +295,7 @@ int launch_thin_w(ThinWArgs a, int64_t ws_floats, int64_t* need, hipStream_t st)
     if (a.ws == nullptr || ws_floats < want) return 1;  // not served without its slices (GAN_OK is 0; the caller maps 1 -> 0)
     hipLaunchKernelGGL((conv_thin_wgrad_k<CIN, COUT, KS, TH, WT>), dim3((unsigned)grid), dim3(256), 0, st, a);
     GAN_CHECK_LAUNCH("conv2d_wgrad(thin)");
-    return gan_finalize_dw(a.ws, (int)(grid * C::WR), KS * KS, a.Cout, a.Cin, a.dwo, a.fu.gain, st);
+    return gan_finalize_dw(a.ws, (int)grid, KS * KS, a.Cout, a.Cin, a.dwo, a.fu.gain, st);
 }
 
 template <int CIN, int COUT>

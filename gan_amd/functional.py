@@ -222,9 +222,10 @@ def raw_chan_dot(A: Tensor, B: Optional[Tensor], b_mode: int, ymask: Optional[Te
     # Always reduce per sample in the kernel: N x fewer workgroups add into one address (a batch-wide sum
     # straight from the kernel is bound by fp32-atomic contention, 0.08-0.17 TB/s measured); the (N, C)
     # partials are folded over N by one tiny reduction.
-    # partials are folded over N by one tiny reduction.  Small tensors (the wide layers' 4x4 .. 16x16 maps) add
-    # straight into (C,): there the extra launch costs more than the contention.
-    direct = not per_sample and A.numel() <= (1 << 21)
+    # partials are folded over N by one tiny reduction.  Small batches of small maps add straight into (C,):
+    # with few adders per address the extra launch costs more than the contention (at N = 256 it does not:
+    # 59 us against 13 us for 512 channels on 4x4).
+    direct = not per_sample and n <= 32 and A.numel() <= (1 << 21)
     out = torch.empty((c,) if direct else (n, c), dtype=torch.float32, device=A.device)
     check(
         _run(
