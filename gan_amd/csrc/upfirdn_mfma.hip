@@ -26,6 +26,7 @@ struct FirArgs {
     int TH, ncg_log2, KC, RWr, RHmax, tiles_x, tiles_y, xstep, ncols, ncb;
     int64_t ntiles;
     unsigned rw_magic;  // ceil(2^32 / RWr)
+    unsigned x_bytes;   // < 2^31: 32-bit buffer offsets
 };
 
 __device__ __forceinline__ bf16x8 fir_tr_frag(const char* p) {
@@ -39,7 +40,9 @@ __device__ __forceinline__ bf16x8 fir_tr_frag(const char* p) {
 }
 
 
-__global__ void __launch_bounds__(256, 4) upfirdn2d_mfma_k(const FirArgs p) {
+// U: 16-byte chunks of the input region per lane (ceil(region chunks / 256)), all of them in flight in registers
+template <int U>
+__global__ void __launch_bounds__(256, U <= 6 ? 4 : 3) upfirdn2d_mfma_k(const FirArgs p) {
     extern __shared__ __attribute__((aligned(256))) char fir_lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     // wave-uniform by construction: as an SGPR the row / region arithmetic below runs on the scalar unit
@@ -86,38 +89,67 @@ __global__ void __launch_bounds__(256, 4) upfirdn2d_mfma_k(const FirArgs p) {
         oy0 = ty * p.TH;
         ox0 = (rem - ty * p.tiles_x) * 32;
     };
-    // input region (zero outside the image and in the columns that only meet zero taps) -> LDS
-    auto load_region = [&](int n, int cb, int oy0, int ox0, int iy0) {
+    // Input region (zero outside the image and in the columns that only meet zero taps) -> registers -> LDS.
+    // `issue` starts the loads of a tile's region (branch-free buffer loads: chunks outside the image read
+    // zeros at an out-of-range offset), `commit` parks them in LDS one tile later: the next tile's HBM round
+    // trip runs under this tile's MFMAs and stores.  (Ablations at 32x16x1024x1024: loads + stores alone took
+    // 506 us of the 671 us the load -> barrier -> compute -> store sequence took; compute + stores alone 335.)
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    constexpr unsigned INV = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.x), 0, p.x_bytes, 0x00020000);
+    const int sh = p.ncg_log2 + 4;  // 8 * CP chunks per group of 8 pixels
+    v4u pre[U];
+    int pre_npix = 0;
+    auto issue = [&](int n, int cb, int oy0, int ox0) {
+        const int iy0 = (oy0 * down - p.py1 + up - 1) >> p.up_log2;
         const int bx0 = ox0 * down - p.px1;
         const int ix0 = (bx0 + up - 1) >> p.up_log2;
         const int iy1 = ((oy0 + p.TH - 1) * down - p.py1 + p.ky - 1) >> p.up_log2;
         const int npix = (iy1 - iy0 + 1) * p.RWr;
-        const int nchunk = ((npix + 7) >> 3) * 8 * CP;
-        // uniform 64-bit base of the region's first pixel, 32-bit per-lane offsets from it
-        const bf16* __restrict__ xb = p.x + (((int64_t)n * p.H + iy0) * p.W + ix0) * p.C + (int64_t)cb * ncg * 16;
-        const int sh = p.ncg_log2 + 4;  // 8 * CP chunks per group of 8 pixels
-        for (int idx = tid; idx < nchunk; idx += 256) {
+        pre_npix = npix;
+        // wave-uniform byte offset of the region's first pixel (may be negative: folded into the lane offset)
+        const int base = (((n * p.H + iy0) * p.W + ix0) * p.C + cb * ncg * 16) * 2;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int idx = u * 256 + tid;
             const int p8 = idx >> sh, r8 = idx & ((1 << sh) - 1);
             const int c8 = r8 >> 3;
             const int pix = p8 * 8 + (r8 & 7);
-            if (pix >= npix) continue;
-            const int ry = (int)__umulhi((unsigned)pix, p.rw_magic), rx = pix - ry * p.RWr;  // pix / RWr, exact for pix < 2^16
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (rx < p.ncols && (unsigned)(iy0 + ry) < (unsigned)p.H && (unsigned)(ix0 + rx) < (unsigned)p.W)
-                v = *reinterpret_cast<const uint4*>(xb + ((ry * p.W + rx) * p.C + c8 * 8));
-            *reinterpret_cast<uint4*>(reg + (c8 >> 1) * PL + pix * 32 + (c8 & 1) * 16) = v;
+            const int ry = (int)__umulhi((unsigned)pix, p.rw_magic), rx_ = pix - ry * p.RWr;  // pix / RWr, exact for pix < 2^16
+            const bool ok = pix < npix && rx_ < p.ncols && (unsigned)(iy0 + ry) < (unsigned)p.H && (unsigned)(ix0 + rx_) < (unsigned)p.W;
+            pre[u] = __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? (unsigned)(base + ((ry * p.W + rx_) * p.C + c8 * 8) * 2) : INV, 0, 0);
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int idx = u * 256 + tid;
+            const int p8 = idx >> sh, r8 = idx & ((1 << sh) - 1);
+            const int c8 = r8 >> 3;
+            const int pix = p8 * 8 + (r8 & 7);
+            if (pix < pre_npix) *reinterpret_cast<v4u*>(reg + (c8 >> 1) * PL + pix * 32 + (c8 & 1) * 16) = pre[u];
         }
     };
 
     const int rows_per_wave = 4 >> p.ncg_log2;
     const int lane_off = (4 * g + q) * 32 + pp * 8;
+    if (t0 < t1) {
+        int n, cb, oy0, ox0;
+        decode(t0, n, cb, oy0, ox0);
+        issue(n, cb, oy0, ox0);
+    }
     for (int64_t t = t0; t < t1; ++t) {
         int n, cb, oy0, ox0;
         decode(t, n, cb, oy0, ox0);
         const int iy0 = (oy0 * down - p.py1 + up - 1) >> p.up_log2;
         __syncthreads();  // previous tile's fragment reads (and the tap matrices' stores) are done
-        load_region(n, cb, oy0, ox0, iy0);
+        commit();
         __syncthreads();
+        if (t + 1 < t1) {
+            int n2, cb2, oy2, ox2;
+            decode(t + 1, n2, cb2, oy2, ox2);
+            issue(n2, cb2, oy2, ox2);
+        }
         // 8 output fragments (16 ch x 16 px) per wave: f -> (row, x half, channel group)
         f32x4 acc[8];
 #pragma unroll
@@ -165,6 +197,7 @@ int gan_upfirdn2d_mfma(const void* x, const float* taps, void* y, int N, int H, 
     if ((C & 15) || (up != 1 && up != 2) || (down != 1 && down != 2)) return 0;
     if (Wo < 16 || Ho < 2 || ky > 16 || kx > 16 || N > 65535 || C / 16 > 65535) return 0;
     if ((((uintptr_t)x) & 15) || (((uintptr_t)y) & 7)) return 0;
+    if ((int64_t)N * H * W * C * 2 >= (1LL << 31)) return 0;  // 32-bit buffer offsets in the region loads
     const int kneed = (15 * down + kx - 1) / up;  // largest input offset inside a 16-pixel output group
     if (kneed > 63) return 0;
     FirArgs a;
@@ -197,7 +230,17 @@ int gan_upfirdn2d_mfma(const void* x, const float* taps, void* y, int N, int H, 
     if (per_cu > 4) per_cu = 4;
     int64_t grid = 256LL * per_cu;
     if (grid > a.ntiles) grid = a.ntiles;
-    hipLaunchKernelGGL(upfirdn2d_mfma_k, dim3((unsigned)grid), dim3(256), (size_t)lds, st, a);
+    a.x_bytes = (unsigned)((int64_t)N * H * W * C * 2);
+    const int nchunk_max = ((a.RHmax * a.RWr + 7) >> 3) * 8 * (2 << ncg_log2);
+    const int slots = (nchunk_max + 255) / 256;
+    if (slots <= 4)
+        hipLaunchKernelGGL(upfirdn2d_mfma_k<4>, dim3((unsigned)grid), dim3(256), (size_t)lds, st, a);
+    else if (slots <= 6)
+        hipLaunchKernelGGL(upfirdn2d_mfma_k<6>, dim3((unsigned)grid), dim3(256), (size_t)lds, st, a);
+    else if (slots <= 9)
+        hipLaunchKernelGGL(upfirdn2d_mfma_k<9>, dim3((unsigned)grid), dim3(256), (size_t)lds, st, a);
+    else
+        return 0;
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         gan_set_error("upfirdn2d(mfma): launch failed: %s", hipGetErrorString(e));
