@@ -781,6 +781,48 @@ extern "C" int gan_mbstd_fwd(const void* x, float* stat, int N, int G, int64_t H
     return GAN_OK;
 }
 
+// Backward of the statistic: gx[j + k*M][e] = gstat[j] * (x_k - mean_e) / (G * std_e * E), with the mean and the
+// standard deviation over the G group members recomputed per element (one thread per (group, element)).
+template <typename T>
+__global__ void __launch_bounds__(TPB) mbstd_bwd_k(const T* __restrict__ x, const float* __restrict__ gstat, T* __restrict__ gx, int M,
+                                                   int G, int64_t E) {
+    const int j = blockIdx.y;
+    const int64_t e = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (e >= E) return;
+    float mean = 0.f;
+    for (int k = 0; k < G; ++k) mean += (float)x[((int64_t)(j + k * M)) * E + e];
+    mean /= (float)G;
+    float var = 0.f;
+    for (int k = 0; k < G; ++k) {
+        const float d = (float)x[((int64_t)(j + k * M)) * E + e] - mean;
+        var = fmaf(d, d, var);
+    }
+    const float f = gstat[j] / ((float)G * sqrtf(var / (float)G + 1e-6f) * (float)E);
+    for (int k = 0; k < G; ++k) {
+        const int64_t o = ((int64_t)(j + k * M)) * E + e;
+        gx[o] = (T)(((float)x[o] - mean) * f);
+    }
+}
+
+extern "C" int gan_mbstd_bwd(const void* x, const float* gstat, void* gx, int N, int G, int64_t HW, int C, int dtype,
+                             gan_stream_t stream) {
+    GAN_CHECK_ARG(x && gstat && gx, "mbstd_bwd: null pointer");
+    GAN_CHECK_ARG(G >= 1 && N > 0 && N % G == 0, "mbstd_bwd: batch %d is not a multiple of group size %d", N, G);
+    GAN_CHECK_ARG(HW > 0 && C > 0, "mbstd_bwd: bad shape");
+    GAN_CHECK_ARG(dtype == GAN_F32 || dtype == GAN_BF16, "mbstd_bwd: bad dtype %d", dtype);
+    hipStream_t st = (hipStream_t)stream;
+    const int M = N / G;
+    const int64_t E = HW * C;
+    GAN_CHECK_ARG(M <= 65535 && ceil_div64(E, TPB) < (1LL << 31), "mbstd_bwd: too large for the grid");
+    const dim3 grid((unsigned)ceil_div64(E, TPB), (unsigned)M);
+    if (dtype == GAN_F32)
+        hipLaunchKernelGGL((mbstd_bwd_k<float>), grid, dim3(TPB), 0, st, (const float*)x, gstat, (float*)gx, M, G, E);
+    else
+        hipLaunchKernelGGL((mbstd_bwd_k<bf16>), grid, dim3(TPB), 0, st, (const bf16*)x, gstat, (bf16*)gx, M, G, E);
+    GAN_CHECK_LAUNCH("mbstd_bwd");
+    return GAN_OK;
+}
+
 // =========================================================================================
 // EMA lerp over one flat fp32 arena (reference: utils.py:95-96)
 // =========================================================================================

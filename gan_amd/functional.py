@@ -988,14 +988,52 @@ class DemodFn(Function):
         return (gs.to(s.dtype) if gs is not None else None), (gw.to(weight.dtype) if gw is not None else None)
 
 
-def minibatch_stddev_stat(x: Tensor, group: int) -> Tensor:
-    """(N/G,) fp32 statistic of MinibatchStdDev (progressive_gan.py:25-36).  The tensor is (N, 512, 4, 4):
-    8 K values per sample, differentiated to second order by R1 -- computed here with a handful of
-    fp32 tensor ops on that tiny tensor (the HIP forward kernel gan_mbstd_fwd serves no-grad calls)."""
+def _mbstd_stat_ops(x: Tensor, group: int) -> Tensor:
     n, c, h, w = x.shape
-    if not torch.is_grad_enabled() or not x.requires_grad:
-        return raw_mbstd_stat(x, group)
     xf = x.float().reshape(group, n // group, c, h, w)
     dev = xf - xf.mean(dim=0, keepdim=True)
     std = (dev.square().sum(dim=0) / group + 1e-6).sqrt()
     return std.mean(dim=(1, 2, 3))
+
+
+class MbstdFn(Function):
+    """(N/G,) fp32 statistic of MinibatchStdDev (progressive_gan.py:25-36): kernel gan_mbstd_fwd forward,
+    gan_mbstd_bwd backward.  Under create_graph (R1 differentiates it to second order) the backward is the
+    same formula written with fp32 tensor ops on this small tensor (N x 512 x 4 x 4), so it can be
+    differentiated again."""
+
+    @staticmethod
+    def forward(ctx, x, group):
+        ctx.save_for_backward(x)
+        ctx.group = group
+        return raw_mbstd_stat(x, group)
+
+    @staticmethod
+    def backward(ctx, gstat):
+        (x,) = ctx.saved_tensors
+        group = ctx.group
+        if torch.is_grad_enabled():
+            # d stat_j / d x_k = dev_k / (G * std * E)  (sum_k dev_k = 0), as tensor ops on x and gstat.  Not a nested
+            # autograd.grad: a re-entrant backward leaves the capturing thread and aborts a HIP-graph capture.
+            n, c, h, w = x.shape
+            xf = x.float().reshape(group, n // group, c, h, w)
+            dev = xf - xf.mean(dim=0, keepdim=True)
+            std = (dev.square().sum(dim=0) / group + 1e-6).sqrt()
+            gx = gstat.float().reshape(1, n // group, 1, 1, 1) * dev / (std * float(group * c * h * w))
+            return gx.reshape(n, c, h, w).to(x.dtype), None
+        lib = _lib.load()
+        xc = as_cl(x.detach())
+        n, c, h, w = xc.shape
+        g32 = _f32(gstat)
+        gx = torch.empty_like(xc)
+        check(lib.gan_mbstd_bwd(ptr(xc), ptr(g32), ptr(gx), n, group, h * w, c, dtype_code(xc), stream_of(xc)), "gan_mbstd_bwd")
+        return gx, None
+
+
+def minibatch_stddev_stat(x: Tensor, group: int) -> Tensor:
+    """(N/G,) fp32 statistic of MinibatchStdDev (progressive_gan.py:25-36)."""
+    if not x.is_cuda:
+        raise _lib.GanAmdError("gan_amd kernels need a CUDA/HIP tensor (no CPU path)")
+    if not torch.is_grad_enabled() or not x.requires_grad:
+        return raw_mbstd_stat(x, group)
+    return MbstdFn.apply(x, group)

@@ -177,6 +177,10 @@ int gan_pad_channels(const void* x, int x_dtype, int64_t sn, int64_t sc, int64_t
  * stat[j] = mean_{c,h,w} sqrt( var_k x[j + k*M] + 1e-6 ),  M = N/G, population variance over the
  * G group members.  x: [N][HW][C]; stat: fp32 [M] (zeroed here). */
 int gan_mbstd_fwd(const void* x, float* stat, int N, int G, int64_t HW, int C, int dtype, gan_stream_t stream);
+/* autograd of the statistic: gx[j + k*M][hw][c] = gstat[j] * (x - mean_k x) / (G * std * HW*C), mean and std over the
+ * G members recomputed per element.  gx: [N][HW][C] in x's dtype (every element written). */
+int gan_mbstd_bwd(const void* x, const float* gstat, void* gx, int N, int G, int64_t HW, int C, int dtype,
+                  gan_stream_t stream);
 
 /* ---- EMA ---------------------------------------------------------------------------------
  * replaces the per-parameter lerp_ loop of EMA.step   utils.py:95-96

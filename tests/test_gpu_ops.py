@@ -644,3 +644,39 @@ def test_conv2d_full_window_kernel(dev, case, dtype):
     gx2, gw2 = torch.autograd.grad(o2.square().sum(), (xr2, wr2))
     assert rel_err(out, o2) < tol
     assert rel_err(gx, gx2) < 2 * tol and rel_err(gw, gw2) < 2 * tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(8, 5, 4, 4, 4), (16, 512, 4, 4, 4), (6, 24, 3, 5, 2)])
+def test_mbstd_backward_kernel(dev, shape, dtype):
+    """gan_mbstd_bwd (first-order backward of the MinibatchStdDev statistic) against autograd of the fp64 formula
+    (progressive_gan.py:25-36); under create_graph the same Function must stay differentiable."""
+    import gan_amd.functional as GF
+
+    n, c, h, w, group = shape
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(n, c, h, w, generator=g).to(dev).to(dtype).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    coef = torch.randn(n // group, generator=g).to(dev)
+    xr = x.detach().double().cpu().requires_grad_(True)
+
+    def ref_stat(t):
+        tf = t.reshape(group, n // group, c, h, w)
+        d = tf - tf.mean(0, keepdim=True)
+        return (d.square().sum(0) / group + 1e-6).sqrt().mean(dim=(1, 2, 3))
+
+    stat = GF.minibatch_stddev_stat(x, group)
+    want = ref_stat(xr)
+    assert rel_err(stat, want) < TOL32
+    (gx,) = torch.autograd.grad((stat * coef).sum(), x)                       # kernel path
+    (gr,) = torch.autograd.grad((want * coef.double().cpu()).sum(), xr, create_graph=True)
+    tol = TOL32 if dtype == torch.float32 else TOLBF
+    assert rel_err(gx, gr) < tol
+    if dtype == torch.float32:
+        stat = GF.minibatch_stddev_stat(x, group)
+        (g1,) = torch.autograd.grad((stat * coef).sum(), x, create_graph=True)  # differentiable path
+        assert rel_err(g1, gr) < TOL32
+        (g2,) = torch.autograd.grad(g1.square().sum(), x)
+        (g2r,) = torch.autograd.grad(gr.square().sum(), xr)
+        # the second derivative carries 1/std^3: elements whose group variance is tiny make it ill-conditioned in
+        # fp32 (the reference formula in plain fp32 tensor ops is itself 1.2e-3 off its fp64 evaluation on this data)
+        assert rel_err(g2, g2r) < 5e-3
