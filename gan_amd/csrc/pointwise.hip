@@ -863,10 +863,8 @@ extern "C" int gan_ema_lerp(float* ema, const float* p, int64_t n, float weight,
 // dtype; `transposed` packs the flipped, channel-swapped weights of the input-gradient correlation
 // (rows = Cin, ci <- co, tap <- kh*kw-1-tap).  One launch instead of flip + permute + pad + cast.
 template <typename TI, typename TO>
-__global__ void __launch_bounds__(256) pack_weight_k(const TI* __restrict__ w, TO* __restrict__ out, int Cout, int Cin, int taps,
-                                                     int rows, int cols, int cols_p, int Kpad, int transposed) {
-    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= (int64_t)rows * Kpad) return;
+__device__ __forceinline__ void pack_weight_elem(const TI* __restrict__ w, TO* __restrict__ out, int64_t e, int Cin, int taps, int cols,
+                                                 int cols_p, int Kpad, int transposed) {
     const int r = (int)(e / Kpad), k = (int)(e - (int64_t)r * Kpad);
     const int tap = k / cols_p, c = k - tap * cols_p;
     float v = 0.f;
@@ -876,6 +874,26 @@ __global__ void __launch_bounds__(256) pack_weight_k(const TI* __restrict__ w, T
         v = (float)w[((int64_t)co * Cin + ci) * taps + t];
     }
     out[e] = (TO)v;
+}
+
+template <typename TI, typename TO>
+__global__ void __launch_bounds__(256) pack_weight_k(const TI* __restrict__ w, TO* __restrict__ out, int Cout, int Cin, int taps,
+                                                     int rows, int cols, int cols_p, int Kpad, int transposed) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (int64_t)rows * Kpad) return;
+    pack_weight_elem<TI, TO>(w, out, e, Cin, taps, cols, cols_p, Kpad, transposed);
+}
+
+// both orientations of one weight in one launch: [0, n0) -> the forward image, [n0, n0 + n1) -> the transposed one
+template <typename TI, typename TO>
+__global__ void __launch_bounds__(256) pack_weight_pair_k(const TI* __restrict__ w, TO* __restrict__ out, TO* __restrict__ out_t, int Cout,
+                                                          int Cin, int taps, int cols_p, int Kpad, int cols_p_t, int Kpad_t) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t n0 = (int64_t)Cout * Kpad, n1 = (int64_t)Cin * Kpad_t;
+    if (e < n0)
+        pack_weight_elem<TI, TO>(w, out, e, Cin, taps, Cin, cols_p, Kpad, 0);
+    else if (e < n0 + n1)
+        pack_weight_elem<TI, TO>(w, out_t, e - n0, Cin, taps, Cout, cols_p_t, Kpad_t, 1);
 }
 
 extern "C" int gan_pack_weight(const void* w, int w_dtype, void* out, int out_dtype, int Cout, int Cin, int kh, int kw,
@@ -900,6 +918,28 @@ extern "C" int gan_pack_weight(const void* w, int w_dtype, void* out, int out_dt
     return GAN_OK;
 }
 
+
+extern "C" int gan_pack_weight_pair(const void* w, int w_dtype, void* out, int cols_p, int Kpad, void* out_t, int cols_p_t, int Kpad_t,
+                                    int out_dtype, int Cout, int Cin, int kh, int kw, gan_stream_t stream) {
+    GAN_CHECK_ARG(w && out && out_t, "pack_weight_pair: null pointer");
+    GAN_CHECK_ARG((w_dtype == GAN_F32 || w_dtype == GAN_BF16) && (out_dtype == GAN_F32 || out_dtype == GAN_BF16), "pack_weight_pair: bad dtype");
+    GAN_CHECK_ARG(Cout > 0 && Cin > 0 && kh > 0 && kw > 0, "pack_weight_pair: bad shape");
+    const int taps = kh * kw;
+    GAN_CHECK_ARG(cols_p >= Cin && Kpad >= taps * cols_p && cols_p_t >= Cout && Kpad_t >= taps * cols_p_t, "pack_weight_pair: padded sizes too small");
+    const int64_t total = (int64_t)Cout * Kpad + (int64_t)Cin * Kpad_t;
+    const int64_t blocks = ceil_div64(total, 256);
+    GAN_CHECK_ARG(blocks < (1LL << 31), "pack_weight_pair: too large");
+    hipStream_t st = (hipStream_t)stream;
+#define PACK2_LAUNCH(TI, TO) \
+    hipLaunchKernelGGL((pack_weight_pair_k<TI, TO>), dim3((unsigned)blocks), dim3(256), 0, st, (const TI*)w, (TO*)out, (TO*)out_t, Cout, Cin, taps, cols_p, Kpad, cols_p_t, Kpad_t)
+    if (w_dtype == GAN_F32 && out_dtype == GAN_BF16) PACK2_LAUNCH(float, bf16);
+    else if (w_dtype == GAN_F32) PACK2_LAUNCH(float, float);
+    else if (out_dtype == GAN_BF16) PACK2_LAUNCH(bf16, bf16);
+    else PACK2_LAUNCH(bf16, float);
+#undef PACK2_LAUNCH
+    GAN_CHECK_LAUNCH("pack_weight_pair");
+    return GAN_OK;
+}
 
 // ---- image-like tensors (C < 8: RGB) -> channels-last, channel-padded, compute dtype ------------
 // out[n][h][w][0..Cp) = x[n][c][h][w] for c < C, zeros above; x has arbitrary element strides (NCHW or

@@ -363,10 +363,34 @@ def _pack_weight(weight: Tensor, dtype: torch.dtype, cin_mult: int, transposed: 
 _PACK_CACHE: dict = {}
 
 
+def _pack_weight_pair(weight: Tensor, dtype: torch.dtype, mult_f: int, mult_t: int):
+    """Both GEMM-B images of one weight in one launch: ((wt, cols_p, kpad), (wt_transposed, cols_p_t, kpad_t))."""
+    cout, cin, kh, kw = weight.shape
+    cp_f = cin + ((-cin) % mult_f)
+    cp_t = cout + ((-cout) % mult_t)
+    kf, kt = kh * kw * cp_f, kh * kw * cp_t
+    kpad_f, kpad_t = kf + ((-kf) % 32), kt + ((-kt) % 32)
+    weight = weight.contiguous()
+    out_f = torch.empty((cout, kpad_f), dtype=dtype, device=weight.device)
+    out_t = torch.empty((cin, kpad_t), dtype=dtype, device=weight.device)
+    check(
+        _lib.load().gan_pack_weight_pair(ptr(weight), dtype_code(weight), ptr(out_f), cp_f, kpad_f, ptr(out_t), cp_t, kpad_t,
+                                         dtype_code(out_f), cout, cin, kh, kw, stream_of(weight)),
+        "gan_pack_weight_pair",
+    )
+    return (out_f, cp_f, kpad_f), (out_t, cp_t, kpad_t)
+
+
+# orientations (cin_mult, transposed) each parameter has been asked for: a layer that trains needs both, and
+# then one launch packs both (survives _PACK_CACHE.clear(): it holds no device memory)
+_PACK_SEEN: dict = {}
+
+
 def pack_weight(weight: Tensor, dtype: torch.dtype, cin_mult: int = 8, transposed: bool = False) -> Tuple[Tensor, int, int]:
     """(Cout, Cin, kh, kw) -> GEMM-B layout [Cout][Kpad], k = tap*Cin_p + ci, zero padded; returns (wt, Cin_p, Kpad).
     `transposed` packs the flipped, channel-swapped weights of the input-gradient correlation."""
-    if not (weight.is_leaf and weight.requires_grad) or weight.numel() == 0:
+    cacheable = weight.is_leaf and (weight.requires_grad or isinstance(weight, torch.nn.Parameter)) and weight.numel() > 0
+    if not cacheable:
         return _pack_weight(weight.detach(), dtype, cin_mult, transposed)
     key = (id(weight), dtype, cin_mult, transposed)
     hit = _PACK_CACHE.get(key)
@@ -376,8 +400,22 @@ def pack_weight(weight: Tensor, dtype: torch.dtype, cin_mult: int = 8, transpose
     PACK_STATS[1] += 1
     if len(_PACK_CACHE) > 4096:
         _PACK_CACHE.clear()
+    if len(_PACK_SEEN) > 4096:
+        _PACK_SEEN.clear()
+    seen = _PACK_SEEN.get((id(weight), dtype))
+    if seen is None or seen[0]() is not weight:
+        seen = _PACK_SEEN[(id(weight), dtype)] = (weakref.ref(weight), set())
+    seen[1].add((cin_mult, transposed))
+    other = [mt for mt in seen[1] if mt[1] != transposed]
+    ref, ver = weakref.ref(weight), weight._version
+    if len(other) == 1 and len(seen[1]) == 2 and weight.dtype in (torch.float32, torch.bfloat16):
+        mult_f, mult_t = (other[0][0], cin_mult) if transposed else (cin_mult, other[0][0])
+        img_f, img_t = _pack_weight_pair(weight.detach(), dtype, mult_f, mult_t)
+        _PACK_CACHE[(id(weight), dtype, mult_f, False)] = (ref, ver, img_f)
+        _PACK_CACHE[(id(weight), dtype, mult_t, True)] = (ref, ver, img_t)
+        return img_t if transposed else img_f
     packed = _pack_weight(weight.detach(), dtype, cin_mult, transposed)
-    _PACK_CACHE[key] = (weakref.ref(weight), weight._version, packed)
+    _PACK_CACHE[key] = (ref, ver, packed)
     return packed
 
 

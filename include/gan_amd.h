@@ -163,6 +163,10 @@ int gan_conv2d_wgrad(const void* x, const void* gy, float* dw, int Cout_out, int
  * tap reversed).  Host-side glue of the reference (the weight is used as is by F.conv2d, stylegan2.py:36). */
 int gan_pack_weight(const void* w, int w_dtype, void* out, int out_dtype, int Cout, int Cin, int kh, int kw, int cols_p,
                     int Kpad, int transposed, gan_stream_t stream);
+/* Both images of one weight in one launch: `out` as gan_pack_weight(..., transposed = 0) with (cols_p, Kpad), `out_t`
+ * as transposed = 1 with (cols_p_t, Kpad_t).  Every layer that trains uses both (forward + input gradient). */
+int gan_pack_weight_pair(const void* w, int w_dtype, void* out, int cols_p, int Kpad, void* out_t, int cols_p_t, int Kpad_t,
+                         int out_dtype, int Cout, int Cin, int kh, int kw, gan_stream_t stream);
 
 /* Image-like tensors (C < 8: the RGB inputs / outputs of the from-RGB and to-RGB convolutions,
  * progressive_gan.py:61, stylegan2.py:124) -> channels-last, zero padded to Cp channels (multiple of 8), in

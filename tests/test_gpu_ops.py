@@ -680,3 +680,30 @@ def test_mbstd_backward_kernel(dev, shape, dtype):
         # the second derivative carries 1/std^3: elements whose group variance is tiny make it ill-conditioned in
         # fp32 (the reference formula in plain fp32 tensor ops is itself 1.2e-3 off its fp64 evaluation on this data)
         assert rel_err(g2, g2r) < 5e-3
+
+
+@pytest.mark.parametrize("shape", [(32, 16, 3, 3), (16, 3, 1, 1), (1, 512, 4, 4), (24, 40, 3, 3)])
+def test_pack_weight_pair(dev, shape):
+    """Both GEMM-B images of a parameter from one launch (gan_pack_weight_pair) == the two single packs, bit for bit,
+    and the cache switches to the paired launch once a parameter has been asked for in both orientations."""
+    import gan_amd.functional as GF
+
+    g = torch.Generator().manual_seed(2)
+    w = torch.nn.Parameter(torch.randn(*shape, generator=g).to(dev))
+    cout, cin = shape[0], shape[1]
+    mf, mt = (16 if cin < 8 else 8), (16 if cout < 8 else 8)
+    for dtype in (torch.bfloat16, torch.float32):
+        GF._PACK_CACHE.clear()
+        GF._PACK_SEEN.clear()
+        f0 = GF._pack_weight(w.detach(), dtype, mf, False)
+        t0 = GF._pack_weight(w.detach(), dtype, mt, True)
+        GF.pack_weight(w, dtype, mf, False)   # single
+        GF.pack_weight(w, dtype, mt, True)    # single; both orientations known from here on
+        with torch.no_grad():
+            w.add_(0.0)                       # version bump: both images are stale
+        miss0 = GF.PACK_STATS[1]
+        f1 = GF.pack_weight(w, dtype, mf, False)
+        t1 = GF.pack_weight(w, dtype, mt, True)
+        assert GF.PACK_STATS[1] == miss0 + 1  # one (paired) launch served both
+        for a, b in ((f0, f1), (t0, t1)):
+            assert a[1:] == b[1:] and torch.equal(a[0], b[0])
