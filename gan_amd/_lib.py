@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GAN_AMD_LIB") or os.path.join(_HERE, "libgan_amd.so")
 
 GAN_F32, GAN_BF16 = 0, 1
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 _SIGNATURES = {
     "gan_amd_version": (c_int, []),
@@ -48,6 +48,7 @@ _SIGNATURES = {
     "gan_pack_weight": (c_int, [c_void_p, c_int, c_void_p, c_int] + [c_int] * 7 + [c_void_p]),
     "gan_pad_channels": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int64, c_int64, c_void_p, c_int] + [c_int] * 5 + [c_void_p]),
     "gan_pack_weight_pair": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int] + [c_int] * 5 + [c_void_p]),
+    "gan_up2_add": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "gan_mbstd_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_int, c_void_p]),
     "gan_mbstd_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_int, c_void_p]),
     "gan_ema_lerp": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_void_p]),

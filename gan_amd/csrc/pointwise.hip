@@ -941,6 +941,56 @@ extern "C" int gan_pack_weight_pair(const void* w, int w_dtype, void* out, int c
     return GAN_OK;
 }
 
+// ---- RGB skip of the generator: out = nearest_up2(lo) + hi  (stylegan2.py:99) ---------------------
+// One pass instead of an upsampling pass that materialises the 4x tensor and an add pass.  Rows are treated as
+// flat runs of 2W*C elements, V per thread (16 bytes of hi / out); the matching elements of the half-resolution
+// row are a gather of V scalars from a row that stays in cache.
+template <typename T, int V>
+__global__ void __launch_bounds__(TPB) up2_add_k(const T* __restrict__ lo, const T* __restrict__ hi, T* __restrict__ out, int W, int C,
+                                                 int64_t rows /* N * 2H */, int H2) {
+    const int rowlen = 2 * W * C;
+    const int per_row = rowlen / V;
+    const int64_t t = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (t >= rows * per_row) return;
+    const int64_t row = t / per_row;
+    const int e0 = (int)(t - row * per_row) * V;
+    const int64_t n = row / H2;
+    const int y = (int)(row - n * H2);
+    const T* __restrict__ lrow = lo + ((n * (H2 >> 1) + (y >> 1)) * W) * (int64_t)C;
+    float h[V];
+    load_f<T, V>(hi + row * rowlen + e0, h);
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+        const int e = e0 + j;
+        const int x = e / C, c = e - x * C;
+        h[j] += (float)lrow[(x >> 1) * C + c];
+    }
+    store_f<T, V>(out + row * rowlen + e0, h);
+}
+
+extern "C" int gan_up2_add(const void* lo, const void* hi, void* out, int N, int H, int W, int C, int dtype, gan_stream_t stream) {
+    GAN_CHECK_ARG(lo && hi && out, "up2_add: null pointer");
+    GAN_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0, "up2_add: bad shape");
+    GAN_CHECK_ARG(dtype == GAN_F32 || dtype == GAN_BF16, "up2_add: bad dtype %d", dtype);
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t rows = (int64_t)N * 2 * H;
+    const int rowlen = 2 * W * C;
+    const int VV = dtype == GAN_F32 ? VecOf<float>::V : VecOf<bf16>::V;
+    const bool vec = (rowlen % VV) == 0 && ((uintptr_t)hi % 16) == 0 && ((uintptr_t)out % 16) == 0;
+    const int64_t threads = rows * (vec ? rowlen / VV : rowlen);
+    const int64_t blocks = ceil_div64(threads, TPB);
+    GAN_CHECK_ARG(blocks < (1LL << 31), "up2_add: tensor too large");
+    if (dtype == GAN_F32) {
+        if (vec) hipLaunchKernelGGL((up2_add_k<float, VecOf<float>::V>), dim3((unsigned)blocks), dim3(TPB), 0, st, (const float*)lo, (const float*)hi, (float*)out, W, C, rows, 2 * H);
+        else hipLaunchKernelGGL((up2_add_k<float, 1>), dim3((unsigned)blocks), dim3(TPB), 0, st, (const float*)lo, (const float*)hi, (float*)out, W, C, rows, 2 * H);
+    } else {
+        if (vec) hipLaunchKernelGGL((up2_add_k<bf16, VecOf<bf16>::V>), dim3((unsigned)blocks), dim3(TPB), 0, st, (const bf16*)lo, (const bf16*)hi, (bf16*)out, W, C, rows, 2 * H);
+        else hipLaunchKernelGGL((up2_add_k<bf16, 1>), dim3((unsigned)blocks), dim3(TPB), 0, st, (const bf16*)lo, (const bf16*)hi, (bf16*)out, W, C, rows, 2 * H);
+    }
+    GAN_CHECK_LAUNCH("up2_add");
+    return GAN_OK;
+}
+
 // ---- image-like tensors (C < 8: RGB) -> channels-last, channel-padded, compute dtype ------------
 // out[n][h][w][0..Cp) = x[n][c][h][w] for c < C, zeros above; x has arbitrary element strides (NCHW or
 // channels-last, fp32 or bf16).  One pass instead of cast + layout copy + zero fill + strided copy (the

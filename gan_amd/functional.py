@@ -920,6 +920,38 @@ def nearest_up2(x: Tensor) -> Tensor:
     return UpFirDnFn.apply(x, _ones_taps(x, 1.0), 2, 1, 1, 0, 1, 0)
 
 
+class Up2AddFn(Function):
+    """nearest_up2(lo) + hi in one pass (the generator's RGB skip, stylegan2.py:99).  Backward: hi's gradient is g
+    itself, lo's is the 2x2 block sum of g (UpFirDnFn, so it can be differentiated again)."""
+
+    @staticmethod
+    def forward(ctx, lo, hi):
+        require_gpu(lo, hi)
+        lo_c = as_cl(lo.detach())
+        hi_c = as_cl(hi.detach().to(lo_c.dtype))
+        n, c, h, w = lo_c.shape
+        if tuple(hi_c.shape) != (n, c, 2 * h, 2 * w):
+            raise _lib.GanAmdError(f"up2_add: hi shape {tuple(hi_c.shape)} is not twice lo's {tuple(lo_c.shape)}")
+        out = torch.empty_like(hi_c)
+        check(
+            _run("up2_add", 0, _nbytes(lo_c, hi_c, out),
+                 lambda: _lib.load().gan_up2_add(ptr(lo_c), ptr(hi_c), ptr(out), n, h, w, c, dtype_code(lo_c), stream_of(lo_c)), (n, c, h, w)),
+            "gan_up2_add",
+        )
+        ctx.hi_dtype = hi.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g_lo = UpFirDnFn.apply(g, _ones_taps(g, 1.0), 1, 2, 0, 0, 0, 0) if _need(ctx, 0) else None
+        g_hi = g.to(ctx.hi_dtype) if _need(ctx, 1) else None
+        return g_lo, g_hi
+
+
+def up2_add(lo: Tensor, hi: Tensor) -> Tensor:
+    return Up2AddFn.apply(lo, hi)
+
+
 def avg_pool2(x: Tensor) -> Tensor:
     """nn.AvgPool2d(2) as upfirdn2d(ones(2,2)/4, down=2, no pad)."""
     return UpFirDnFn.apply(x, _ones_taps(x, 0.25), 1, 2, 0, 0, 0, 0)

@@ -256,5 +256,5 @@ class StyleGan2Generator(nn.Module):
         for block in self.blocks[1:]:
             x, new_y = block(x, w)
             # RGB skip: y = upsample(y) + new_y (stylegan2.py:99) in one fused pass
-            y = GF.affine_act(GF.nearest_up2(y), r=new_y)
+            y = GF.up2_add(y, new_y)
         return y

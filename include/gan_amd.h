@@ -176,6 +176,10 @@ int gan_pack_weight_pair(const void* w, int w_dtype, void* out, int cols_p, int 
 int gan_pad_channels(const void* x, int x_dtype, int64_t sn, int64_t sc, int64_t sh, int64_t sw, void* out, int out_dtype,
                      int N, int C, int H, int W, int Cp, gan_stream_t stream);
 
+/* RGB skip of StyleGan2Generator.forward (stylegan2.py:99): out = nearest_up2(lo) + hi in one pass.
+ * lo: [N][H][W][C], hi / out: [N][2H][2W][C], same dtype. */
+int gan_up2_add(const void* lo, const void* hi, void* out, int N, int H, int W, int C, int dtype, gan_stream_t stream);
+
 /* ---- MinibatchStdDev ---------------------------------------------------------------------
  * replaces MinibatchStdDev.forward   modelling/progressive_gan.py:20-36
  * stat[j] = mean_{c,h,w} sqrt( var_k x[j + k*M] + 1e-6 ),  M = N/G, population variance over the

@@ -707,3 +707,24 @@ def test_pack_weight_pair(dev, shape):
         assert GF.PACK_STATS[1] == miss0 + 1  # one (paired) launch served both
         for a, b in ((f0, f1), (t0, t1)):
             assert a[1:] == b[1:] and torch.equal(a[0], b[0])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(3, 3, 4, 4), (2, 3, 16, 24), (2, 16, 8, 8), (1, 5, 3, 7)])
+def test_up2_add_kernel(dev, shape, dtype):
+    """gan_up2_add: nearest_up2(lo) + hi (the generator's RGB skip, stylegan2.py:99) and its gradients."""
+    import gan_amd.functional as GF
+
+    n, c, h, w = shape
+    g = torch.Generator().manual_seed(9)
+    lo = torch.randn(n, c, h, w, generator=g).to(dev).to(dtype).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    hi = torch.randn(n, c, 2 * h, 2 * w, generator=g).to(dev).to(dtype).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    out = GF.up2_add(lo, hi)
+    lr, hr = lo.detach().double().cpu().requires_grad_(True), hi.detach().double().cpu().requires_grad_(True)
+    ref = F.interpolate(lr, scale_factor=2.0, mode="nearest") + hr
+    tol = TOL32 if dtype == torch.float32 else TOLBF
+    assert rel_err(out, ref) < tol
+    wgt = torch.randn(out.shape, generator=g).to(dev)
+    g_lo, g_hi = torch.autograd.grad((out.float() * wgt).sum(), (lo, hi))
+    r_lo, r_hi = torch.autograd.grad((ref * wgt.double().cpu()).sum(), (lr, hr))
+    assert rel_err(g_lo, r_lo) < tol and rel_err(g_hi, r_hi) < tol
