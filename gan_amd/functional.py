@@ -390,7 +390,7 @@ def pack_weight(weight: Tensor, dtype: torch.dtype, cin_mult: int = 8, transpose
         return _pack_weight(weight.detach(), dtype, cin_mult, transposed)
     key = (id(weight), dtype, cin_mult, transposed)
     hit = _PACK_CACHE.get(key)
-    if hit is not None and hit[0]() is weight and hit[1] == weight._version:
+    if hit is not None and hit[0]() is weight and hit[1] == (weight._version, weight.data_ptr()):
         PACK_STATS[0] += 1
         return hit[2]
     PACK_STATS[1] += 1
@@ -403,7 +403,7 @@ def pack_weight(weight: Tensor, dtype: torch.dtype, cin_mult: int = 8, transpose
         seen = _PACK_SEEN[(id(weight), dtype)] = (weakref.ref(weight), set())
     seen[1].add((cin_mult, transposed))
     other = [mt for mt in seen[1] if mt[1] != transposed]
-    ref, ver = weakref.ref(weight), weight._version
+    ref, ver = weakref.ref(weight), (weight._version, weight.data_ptr())  # data_ptr: p.data = ... does not bump the version
     if len(other) == 1 and len(seen[1]) == 2 and weight.dtype in (torch.float32, torch.bfloat16):
         mult_f, mult_t = (other[0][0], cin_mult) if transposed else (cin_mult, other[0][0])
         img_f, img_t = _pack_weight_pair(weight.detach(), dtype, mult_f, mult_t)
