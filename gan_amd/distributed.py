@@ -42,7 +42,9 @@ def init_from_env(device_type: Optional[str] = None) -> Tuple[int, int, torch.de
     device = torch.device("cuda", local) if use_gpu else torch.device("cpu")
     if use_gpu:
         torch.cuda.set_device(device)
-    if world > 1 and not dist.is_initialized():
+    # GAN_AMD_FORCE_ALLREDUCE=1 (test aid): bring the process group up even for one rank, so that the RCCL path,
+    # its watchdog thread and the HIP-graph capture meet on a one-GPU box
+    if (world > 1 or os.environ.get("GAN_AMD_FORCE_ALLREDUCE") == "1") and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if use_gpu and not one_gpu:

@@ -9,6 +9,7 @@
 Out of scope here: the CelebA loader, wandb, PNG dumps, FID, DiffAugment.
 """
 import json
+import os
 import time
 from dataclasses import dataclass, field
 from typing import Callable, Dict, Iterator, List, Optional
@@ -154,12 +155,23 @@ class Trainer:
             segments = []  # (graph, reducer whose arena is averaged after it | None)
             pool = torch.cuda.graph_pool_handle()
             torch.cuda.synchronize()
+            # With a process group up, RCCL's watchdog thread polls the events of outstanding collectives.  Under
+            # the default "global" capture mode such a hipEventQuery from another thread is an error that takes the
+            # process down (seen: "operation not permitted when stream is capturing" from ProcessGroupNCCL's
+            # watchdog).  Capture in thread-local mode, and let the watchdog retire what the eager iterations left.
+            import torch.distributed as dist
+
+            if dist.is_available() and dist.is_initialized():
+                import time
+
+                if os.environ.get("GAN_AMD_NO_CAPTURE_SLEEP") != "1":  # (test hook: thread-local mode alone must hold)
+                    time.sleep(0.3)
             done = False
             try:
                 while not done:
                     graph = torch.cuda.CUDAGraph()
                     red = None
-                    with torch.cuda.graph(graph, pool=pool):
+                    with torch.cuda.graph(graph, pool=pool, capture_error_mode="thread_local"):
                         try:
                             red = next(it)
                         except StopIteration as stop:
