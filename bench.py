@@ -96,7 +96,7 @@ def roofline_leg(trainer, next_reals):
         torch.cuda.synchronize()
     finally:
         GF.set_profile(None)
-    if os.environ.get("GAN_AMD_BENCH_DETAIL"):
+    if os.environ.get("GAN_AMD_BENCH_DETAIL") and os.environ.get("RANK", "0") == "0":
         rows = sorted(prof.by_shape().items(), key=lambda kv: -kv[1]["ms"])
         with open(os.environ["GAN_AMD_BENCH_DETAIL"], "w") as f:
             for (fam, tag), d in rows:
@@ -249,9 +249,11 @@ def main():
     graphed = bool(cfg.hip_graph and trainer._graph is not None)
 
     roof = fams = micro_res = cpu = None
-    if rank == 0:
-        if not args.no_roofline:
-            roof, fams = roofline_leg(trainer, next_reals)
+    if not args.no_roofline:
+        # every rank runs the event-bracketed iteration (its gradient all-reduces need all of them); rank 0 reports
+        r = roofline_leg(trainer, next_reals)
+        if rank == 0:
+            roof, fams = r
     if world > 1:
         dist.barrier()
     if rank == 0 and world == 1:
