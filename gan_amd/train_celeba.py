@@ -167,6 +167,7 @@ class Trainer:
                 if os.environ.get("GAN_AMD_NO_CAPTURE_SLEEP") != "1":  # (test hook: thread-local mode alone must hold)
                     time.sleep(0.3)
             done = False
+            failed: Optional[BaseException] = None
             try:
                 while not done:
                     graph = torch.cuda.CUDAGraph()
@@ -179,10 +180,19 @@ class Trainer:
                             done = True
                     segments.append((graph, red))
             except Exception as exc:  # capture refused (driver / allocator state): keep training, launched from the host
+                failed = exc
+                it.close()
+            if dist.is_available() and dist.is_initialized():
+                # all ranks replay graphs or none does: the two paths issue different collectives (one flat
+                # all-reduce per network against one per bucket), so a lone fallback would hang the job
+                ok = torch.tensor([0.0 if failed is not None else 1.0], device=self.device)
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                if float(ok.item()) == 0.0 and failed is None:
+                    failed = RuntimeError("another rank could not capture the iteration")
+            if failed is not None:
                 import sys
 
-                print(f"gan_amd: HIP graph capture failed ({type(exc).__name__}: {exc}); continuing without graphs", file=sys.stderr)
-                it.close()
+                print(f"gan_amd: HIP graph capture failed ({type(failed).__name__}: {failed}); continuing without graphs", file=sys.stderr)
                 self.cfg.hip_graph = False
                 self.disc.requires_grad_(True)
                 self.red_d.zero_grad()
