@@ -206,6 +206,10 @@ def cpu_leg(args):
 
 
 def main():
+    if os.environ.get("GAN_AMD_BENCH_WATCHDOG"):  # debugging aid: dump every thread's stack and exit after N seconds
+        import faulthandler
+
+        faulthandler.dump_traceback_later(int(os.environ["GAN_AMD_BENCH_WATCHDOG"]), exit=True)
     args = parse()
     from gan_amd.distributed import init_from_env
     from gan_amd.train_celeba import synthetic_reals
@@ -240,7 +244,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=device if dist.get_backend() != "gloo" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     logs = trainer.train_step(next_reals)  # sanity: losses stay finite

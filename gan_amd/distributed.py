@@ -54,6 +54,31 @@ def init_from_env(device_type: Optional[str] = None) -> Tuple[int, int, torch.de
     return rank, world, device
 
 
+def _via_host(t: Tensor, group=None) -> bool:
+    """gloo with device tensors (the GAN_AMD_ONE_GPU rehearsal: several ranks on one GPU) stages through the host;
+    its own device-tensor path hung in the first broadcast on this ROCm build."""
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
+def all_reduce_sum(t: Tensor, group=None, async_op: bool = False):
+    """dist.all_reduce(SUM) in place; returns the work handle for async_op on RCCL, None otherwise."""
+    if _via_host(t, group):
+        c = t.detach().cpu()
+        dist.all_reduce(c, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(c)
+        return None
+    return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+
+
+def broadcast(t: Tensor, src: int = 0, group=None) -> None:
+    if _via_host(t, group):
+        c = t.detach().cpu()
+        dist.broadcast(c, src=src, group=group)
+        t.copy_(c)
+        return
+    dist.broadcast(t, src=src, group=group)
+
+
 def interleaved_shard(global_batch: int, rank: int, world: int, group_size: int = 4) -> Tensor:
     """Row indices of the global batch owned by `rank`, such that MinibatchStdDev on the local shard sees
     exactly the global groups: rank r owns group columns J_r = [r*M/R, (r+1)*M/R), M = N/group_size, and
@@ -126,7 +151,9 @@ class GradBucketReducer:
         buf = self.arena.grad[start:end]
         # pre-divide so SUM gives the mean on every backend (gloo has no AVG)
         buf.div_(self.world)
-        self._works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        work = all_reduce_sum(buf, group=self.group, async_op=True)
+        if work is not None:
+            self._works.append(work)
 
     def prepare(self) -> None:
         """Arm the hooks for one backward pass.  Parameters that do not require grad (frozen D during

@@ -18,7 +18,7 @@ import torch
 from torch import Tensor, nn
 
 from . import functional as GF
-from .distributed import GradBucketReducer, init_from_env, interleaved_shard
+from .distributed import GradBucketReducer, all_reduce_sum, broadcast, init_from_env, interleaved_shard
 from .losses import get_loss, get_regularizer
 from .modelling import build_discriminator, build_generator
 from .utils import EMA, make_parser, prepare_model
@@ -104,7 +104,7 @@ class Trainer:
 
         for m in (self.disc, self.gen):
             for t in list(m.parameters()) + list(m.buffers()):
-                dist.broadcast(t.data, src=0)
+                broadcast(t.data, src=0)
 
     def train_step(self, next_reals: Callable[[], Tensor]) -> Dict[str, Tensor]:
         """One generator iteration = the `while` body of train_celeba.py:111-149.  `next_reals()` returns
@@ -137,7 +137,7 @@ class Trainer:
             import torch.distributed as dist
 
             red.arena.grad.div_(red.world)
-            dist.all_reduce(red.arena.grad, op=dist.ReduceOp.SUM, group=red.group)
+            all_reduce_sum(red.arena.grad, group=red.group)
 
     # ---- HIP graphs ---------------------------------------------------------------------------------
     def _graph_step(self, next_reals: Callable[[], Tensor]) -> Dict[str, Tensor]:
@@ -185,7 +185,7 @@ class Trainer:
             if dist.is_available() and dist.is_initialized():
                 # all ranks replay graphs or none does: the two paths issue different collectives (one flat
                 # all-reduce per network against one per bucket), so a lone fallback would hang the job
-                ok = torch.tensor([0.0 if failed is not None else 1.0], device=self.device)
+                ok = torch.tensor([0.0 if failed is not None else 1.0], device=self.device if dist.get_backend() != "gloo" else "cpu")
                 dist.all_reduce(ok, op=dist.ReduceOp.MIN)
                 if float(ok.item()) == 0.0 and failed is None:
                     failed = RuntimeError("another rank could not capture the iteration")
