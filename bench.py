@@ -205,7 +205,30 @@ def cpu_leg(args):
                 sample=f"oracle (fp32 PyTorch restatement of the reference) hinge+R1 step, {args.img_size}x{args.img_size}, batch {batch}, {iters} timed iteration(s) after 1 warm-up")
 
 
+_REAL_STDOUT = None
+
+
+def _quiet_stdout():
+    """stdout carries ONE JSON line: everything else that native libraries print there (RCCL's five-line version
+    banner at communicator set-up, for one) is sent to stderr for the length of the run."""
+    global _REAL_STDOUT
+    sys.stdout.flush()
+    _REAL_STDOUT = os.dup(1)
+    os.dup2(2, 1)
+
+
+def _emit(line: dict) -> None:
+    data = (json.dumps(line) + "\n").encode()
+    if _REAL_STDOUT is None:
+        sys.stdout.write(data.decode())
+        sys.stdout.flush()
+    else:
+        sys.stdout.flush()
+        os.write(_REAL_STDOUT, data)
+
+
 def main():
+    _quiet_stdout()
     if os.environ.get("GAN_AMD_BENCH_WATCHDOG"):  # debugging aid: dump every thread's stack and exit after N seconds
         import faulthandler
 
@@ -216,7 +239,7 @@ def main():
 
     rank, world, device = init_from_env("cuda")
     if args.micro_only:
-        print(json.dumps(micro_leg(device)), flush=True)
+        _emit(micro_leg(device))
         return
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE is {world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
@@ -301,7 +324,7 @@ def main():
             "cpu_baseline": cpu,
             "upfirdn2d": micro_res,
         }
-        print(json.dumps(line), flush=True)
+        _emit(line)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
