@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GAN_AMD_LIB") or os.path.join(_HERE, "libgan_amd.so")
 
 GAN_F32, GAN_BF16 = 0, 1
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 _SIGNATURES = {
     "gan_amd_version": (c_int, []),
@@ -40,6 +40,9 @@ _SIGNATURES = {
     ),
     "gan_conv2d_wgrad_workspace": (c_int64, [c_int] * 13),
     "gan_conv2d_wgrad": (c_int, [c_void_p] * 3 + [c_int, c_int, c_void_p] + [c_int] * 12 + [c_void_p, c_int64, c_float, c_int, c_float, c_int, c_void_p]),
+    "gan_amd_init": (c_int, []),
+    "gan_conv2d_wgrad_static_max_floats": (c_int64, []),
+    "gan_conv2d_wgrad_static": (c_int, [c_void_p] * 3 + [c_int, c_int, c_void_p] + [c_int] * 12 + [c_float, c_int, c_float, c_int, c_void_p]),
     "gan_modconv_bwd_pre": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_void_p]),
     "gan_modconv_bwd_post": (c_int, [c_void_p] * 7 + [c_int, c_int, c_void_p]),
     "gan_scale_dot": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_void_p]),

@@ -247,10 +247,10 @@ extern "C" int64_t gan_conv2d_wgrad_workspace(int N, int H, int W, int Cin, int 
     return need > L ? need : L;
 }
 
-extern "C" int gan_conv2d_wgrad(const void* x, const void* gy, float* dw, int Cout_out, int Cin_out, const float* in_scale, int N,
-                                int H, int W, int Cin, int up2, int Ho, int Wo, int Cout, int kh, int kw, int py, int px,
-                                float* workspace, int64_t workspace_floats, float x_slope, int gy_up2, float gain,
-                                int dtype, gan_stream_t stream) {
+static int wgrad_impl(const void* x, const void* gy, float* dw, int Cout_out, int Cin_out, const float* in_scale, int N,
+                      int H, int W, int Cin, int up2, int Ho, int Wo, int Cout, int kh, int kw, int py, int px,
+                      float* workspace, int64_t workspace_floats, float x_slope, int gy_up2, float gain,
+                      int dtype, gan_stream_t stream) {
     GAN_CHECK_ARG(dw && (N == 0 || (x && gy)), "conv2d_wgrad: null pointer");
     GAN_CHECK_ARG(dtype == GAN_F32 || dtype == GAN_BF16, "conv2d_wgrad: bad dtype %d", dtype);
     GAN_CHECK_ARG(N >= 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Ho > 0 && Wo > 0, "conv2d_wgrad: bad shape");
@@ -305,4 +305,67 @@ extern "C" int gan_conv2d_wgrad(const void* x, const void* gy, float* dw, int Co
     const int rc = dtype == GAN_F32 ? launch<float>(a, st) : launch<bf16>(a, st);
     if (rc != GAN_OK) return rc;
     return gan_finalize_dw(workspace, 1, kh * kw, Cout, Cin, dwo, 1.f, st);  // the kernel applied the gain
+}
+
+extern "C" int gan_conv2d_wgrad(const void* x, const void* gy, float* dw, int Cout_out, int Cin_out, const float* in_scale, int N,
+                                int H, int W, int Cin, int up2, int Ho, int Wo, int Cout, int kh, int kw, int py, int px,
+                                float* workspace, int64_t workspace_floats, float x_slope, int gy_up2, float gain,
+                                int dtype, gan_stream_t stream) {
+    return wgrad_impl(x, gy, dw, Cout_out, Cin_out, in_scale, N, H, W, Cin, up2, Ho, Wo, Cout, kh, kw, py, px, workspace,
+                      workspace_floats, x_slope, gy_up2, gain, dtype, stream);
+}
+
+// ---- the entry point that allocates nothing (include/gan_amd.h: gan_conv2d_wgrad_static) ------------------------
+// The split-K slices go to a file-scope device array instead of a caller-owned workspace.  In host code the
+// array's NAME is only a stand-in for the symbol: its device address is resolved once per device with
+// hipGetSymbolAddress (that device current) and kept; every use below goes through that pointer.
+static __device__ __align__(256) float scratch[GAN_WGRAD_STATIC_MAX_FLOATS];
+
+static constexpr int kMaxDevices = 64;
+static float* g_scratch_ptr[kMaxDevices];  // per device: each GPU holds its own copy of the array at its own address
+static int g_scratch_state[kMaxDevices];   // 0 = not resolved, 1 = resolved
+
+static int resolve_scratch(float** out) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) {
+        gan_set_error("conv2d_wgrad_static: no current HIP device (or device index >= %d)", kMaxDevices);
+        return GAN_ERR_LAUNCH;
+    }
+    if (__atomic_load_n(&g_scratch_state[dev], __ATOMIC_ACQUIRE) != 1) {
+        float* p = nullptr;
+        const hipError_t e = hipGetSymbolAddress((void**)&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || p == nullptr) {
+            gan_set_error("conv2d_wgrad_static: hipGetSymbolAddress(scratch) failed on device %d: %s", dev, hipGetErrorString(e));
+            return GAN_ERR_LAUNCH;
+        }
+        g_scratch_ptr[dev] = p;  // racing first calls resolve the same address
+        __atomic_store_n(&g_scratch_state[dev], 1, __ATOMIC_RELEASE);
+    }
+    *out = g_scratch_ptr[dev];
+    return GAN_OK;
+}
+
+extern "C" int gan_amd_init(void) {
+    float* p = nullptr;
+    return resolve_scratch(&p);
+}
+
+extern "C" int64_t gan_conv2d_wgrad_static_max_floats(void) { return (int64_t)GAN_WGRAD_STATIC_MAX_FLOATS; }
+
+extern "C" int gan_conv2d_wgrad_static(const void* x, const void* gy, float* dw, int Cout_out, int Cin_out, const float* in_scale,
+                                       int N, int H, int W, int Cin, int up2, int Ho, int Wo, int Cout, int kh, int kw, int py,
+                                       int px, float x_slope, int gy_up2, float gain, int dtype, gan_stream_t stream) {
+    GAN_CHECK_ARG(dtype == GAN_F32 || dtype == GAN_BF16, "conv2d_wgrad_static: bad dtype %d", dtype);
+    const int64_t need = gan_conv2d_wgrad_workspace(N, H, W, Cin, up2, Ho, Wo, Cout, kh, kw, py, px, dtype);
+    GAN_CHECK_ARG(need <= (int64_t)GAN_WGRAD_STATIC_MAX_FLOATS,
+                  "conv2d_wgrad_static: this shape needs %lld floats of split-K scratch, the built-in buffer holds %lld "
+                  "(use gan_conv2d_wgrad with a caller-owned workspace)",
+                  (long long)need, (long long)GAN_WGRAD_STATIC_MAX_FLOATS);
+    float* ws = nullptr;
+    const int rc = resolve_scratch(&ws);
+    if (rc != GAN_OK) return rc;
+    // Every slice the kernels read they have written in this call (plain stores), and the atomics path clears its one
+    // slice with hipMemsetAsync on `stream` first: nothing of the previous call's contents is read.
+    return wgrad_impl(x, gy, dw, Cout_out, Cin_out, in_scale, N, H, W, Cin, up2, Ho, Wo, Cout, kh, kw, py, px, ws,
+                      (int64_t)GAN_WGRAD_STATIC_MAX_FLOATS, x_slope, gy_up2, gain, dtype, stream);
 }

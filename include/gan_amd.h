@@ -16,7 +16,8 @@
  *    kernels are enqueued on `stream` (a hipStream_t) and the call returns immediately.
  *  - Return value: 0 on success, negative on error; gan_amd_last_error() then describes it
  *    (thread-local).  Nothing is launched when an argument check fails.
- *  - One process per GPU; calls are re-entrant; there is no global mutable state.
+ *  - One process per GPU; calls are re-entrant; there is no global mutable state (one exception, documented at
+ *    gan_conv2d_wgrad_static: the built-in scratch buffer of the entry point that allocates nothing).
  */
 #ifndef GAN_AMD_H
 #define GAN_AMD_H
@@ -156,6 +157,26 @@ int64_t gan_conv2d_wgrad_workspace(int N, int H, int W, int Cin, int up2, int Ho
 int gan_conv2d_wgrad(const void* x, const void* gy, float* dw, int Cout_out, int Cin_out, const float* in_scale, int N, int H, int W, int Cin,
                      int up2, int Ho, int Wo, int Cout, int kh, int kw, int py, int px, float* workspace,
                      int64_t workspace_floats, float x_slope, int gy_up2, float gain, int dtype, gan_stream_t stream);
+
+/* The same weight gradient for callers that cannot allocate (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc).  NO counterpart in the reference: the reference allocates freely through
+ * PyTorch's caching allocator.  Arguments and result are those of gan_conv2d_wgrad without `workspace` /
+ * `workspace_floats`: the split-K slices go to a buffer built into the library, a file-scope device array of
+ * GAN_WGRAD_STATIC_MAX_FLOATS floats (48 MiB; every GPU the library runs on holds its own copy until the process
+ * ends).  The call allocates and frees nothing (no hipMalloc / hipFree, no allocating library routine); shapes whose
+ * gan_conv2d_wgrad_workspace(...) exceeds the buffer are rejected with GAN_ERR_ARG and nothing is launched.
+ * Every call on one GPU shares that GPU's buffer: the kernels overwrite what they read back (the one slice that is
+ * accumulated into is cleared on `stream` first), so consecutive calls on one stream are independent of each other,
+ * but calls that OVERLAP on one GPU (two streams, two threads) race -- serialise them.
+ * gan_amd_init() resolves the buffer's device address for the CURRENT device (hipGetSymbolAddress, once per device);
+ * gan_conv2d_wgrad_static does the same on its first call on a device.  Call gan_amd_init() beforehand where that
+ * first call would fall inside a stream capture. */
+#define GAN_WGRAD_STATIC_MAX_FLOATS 12582912
+int gan_amd_init(void);
+int64_t gan_conv2d_wgrad_static_max_floats(void);
+int gan_conv2d_wgrad_static(const void* x, const void* gy, float* dw, int Cout_out, int Cin_out, const float* in_scale, int N, int H,
+                            int W, int Cin, int up2, int Ho, int Wo, int Cout, int kh, int kw, int py, int px, float x_slope,
+                            int gy_up2, float gain, int dtype, gan_stream_t stream);
 
 /* Packs a (Cout, Cin, kh, kw) weight tensor (w_dtype) into the GEMM-B image the convolutions above take:
  * out[row][Kpad] in out_dtype, k = tap*cols_p + c, zero padded.  transposed = 0: rows = Cout, c = ci;
