@@ -167,7 +167,8 @@ def micro_leg(device):
         rec = {}
         t = timeit(lambda: GF.raw_upfirdn2d(x, k3, 1, 1, 1, 1, h, w), iters)
         rec["fir3_gbs"] = round(4 * numel / t / 1e9, 1)
-        t = timeit(lambda: GF.raw_affine_act(x, b=torch.zeros(c, device=device), slope=0.2), iters)
+        bias = torch.zeros(c, device=device)
+        t = timeit(lambda: GF.raw_affine_act(x, b=bias, slope=0.2), iters)
         rec["bias_lrelu_gbs"] = round(4 * numel / t / 1e9, 1)
         if numel <= (1 << 27):
             t = timeit(lambda: GF.raw_upfirdn2d(x, k4, 2, 1, 2, 2, 2 * h, 2 * w), iters)

@@ -418,6 +418,15 @@ def pack_weight(weight: Tensor, dtype: torch.dtype, cin_mult: int = 8, transpose
 PACK_STATS = [0, 0]  # hits, misses (cacheable tensors only)
 
 
+def invalidate_packed(params) -> None:
+    """Drop the cached GEMM images of `params`: for writers that change a parameter's values behind autograd's
+    back -- through a flat arena or a raw pointer (EMA.step, a graph replay) -- so that neither `_version` nor
+    `data_ptr()` moves and the cache key above would still match."""
+    ids = {id(p) for p in params}
+    for key in [k for k in _PACK_CACHE if k[0] in ids]:
+        del _PACK_CACHE[key]
+
+
 def _wide_kernel_shape(x: Tensor, cin_p: int, cout: int, ho: int, wo: int, kh: int, kw: int, py: int, px: int) -> bool:
     """Mirror of the C-side dispatch (conv_fwd.hip: thin kernel first, then conv_wide.hip's eligibility)."""
     if x.dtype != torch.bfloat16 or cin_p % 64 != 0 or cout % 4 != 0 or x.shape[0] * ho * wo < 128:

@@ -125,6 +125,9 @@ class Trainer:
 
     # ---- eager: gradient buckets are all-reduced from hooks while the backward pass is still running ----
     def _run_eager(self, next_reals: Callable[[], Tensor]) -> Dict[str, Tensor]:
+        if self._graph is not None:  # after graph replays the arenas still hold the last gathered gradients
+            self.red_d.zero_grad()
+            self.red_g.zero_grad()
         it = self._iteration(next_reals, overlap=True)
         try:
             while True:
@@ -195,10 +198,16 @@ class Trainer:
                 print(f"gan_amd: HIP graph capture failed ({type(failed).__name__}: {failed}); continuing without graphs", file=sys.stderr)
                 self.cfg.hip_graph = False
                 self.disc.requires_grad_(True)
-                self.red_d.zero_grad()
-                self.red_g.zero_grad()
+                # what the aborted capture left behind was recorded, never executed: packed weights and padded inputs
+                # that point at graph-pool buffers, gradient tensors handed over by a backward pass that did not run
+                GF._PACK_CACHE.clear()
+                GF._PAD_MEMO.clear()
+                for red in (self.red_d, self.red_g):
+                    red.arena.attach_grads()
+                    red.zero_grad()
                 torch.cuda.synchronize()
-                return self._run_eager(lambda: self._graph_reals[0])
+                feed = iter(self._graph_reals)
+                return self._run_eager(lambda: next(feed).detach())
             self._graph = segments
             # capture does not execute: the replay below runs the iteration on the data just fetched
         else:

@@ -187,8 +187,11 @@ class EMA(nn.Module):
         dst = arena_of(self.ema_model)
         if self._count == self.warmup:
             dst.data.copy_(src.data)
-            return
-        GF.raw_ema_lerp(dst.data, src.data, 1 - self.beta)
+        else:
+            GF.raw_ema_lerp(dst.data, src.data, 1 - self.beta)
+        # both writes go through the arena: no parameter's version moves, so the packed weight images that
+        # gen_ema(z) cached at an earlier step would still match.  Drop them.
+        GF.invalidate_packed(dst.params)
 
     def load_state_dict(self, *args, **kwargs):
         out = super().load_state_dict(*args, **kwargs)

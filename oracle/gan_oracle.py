@@ -82,6 +82,30 @@ def bias_leaky_relu(x: Tensor, bias: Optional[Tensor], slope: float = SLOPE) -> 
     return F.leaky_relu(x, slope)
 
 
+def up_conv_blur(sd: Mapping[str, Tensor], x: Tensor, kernel_size: int, blur_size: Optional[int] = 3) -> Tensor:
+    """The nn.Sequential built by up_conv_blur (nvidia_ops.py:81-101), keys as in its state_dict:
+    blur_size None: Upsample(2) -> Conv2d ("1.*"); kernel_size 1: Conv2d 1x1 ("0.*") -> Blur(up=2);
+    else ConvTranspose2d(stride 2, output_padding k % 2) ("0.*") -> Blur."""
+    pad = (kernel_size - 1) // 2
+    if blur_size is None:
+        return F.conv2d(nearest_up2(x), sd["1.weight"], sd["1.bias"], padding=pad)
+    if kernel_size == 1:
+        return blur(F.conv2d(x, sd["0.weight"], sd["0.bias"]), blur_size, up=2)
+    y = F.conv_transpose2d(x, sd["0.weight"], sd["0.bias"], stride=2, padding=pad, output_padding=kernel_size % 2)
+    return blur(y, blur_size)
+
+
+def blur_conv_down(sd: Mapping[str, Tensor], x: Tensor, kernel_size: int, blur_size: Optional[int] = 3) -> Tensor:
+    """The nn.Sequential built by blur_conv_down (nvidia_ops.py:104-123): blur_size None: Conv2d ("0.*") ->
+    AvgPool2d(2); kernel_size 1: Blur(down=2) -> Conv2d 1x1 ("1.*"); else Blur -> Conv2d(stride 2) ("1.*")."""
+    pad = (kernel_size - 1) // 2
+    if blur_size is None:
+        return avg_pool2(F.conv2d(x, sd["0.weight"], sd["0.bias"], padding=pad))
+    if kernel_size == 1:
+        return F.conv2d(blur(x, blur_size, down=2), sd["1.weight"], sd["1.bias"])
+    return F.conv2d(blur(x, blur_size), sd["1.weight"], sd["1.bias"], stride=2, padding=pad)
+
+
 # --------------------------------------------------------------------------------------
 # modelling/stylegan2.py + modelling/stylegan.py:Noise
 # --------------------------------------------------------------------------------------

@@ -411,8 +411,38 @@ def gold_trajectory():
     )
 
 
+def gold_resample_convs():
+    """up_conv_blur / blur_conv_down (nvidia_ops.py:81-123), all three branches of each (blur_size None, kernel_size 1,
+    kernel_size 3), blur sizes 3 and 4: forward, first-order gradients of every leaf, second order through x."""
+    torch.manual_seed(71)
+    out = {}
+    for fn_name, fn in (("up_conv_blur", ref_ops.up_conv_blur), ("blur_conv_down", ref_ops.blur_conv_down)):
+        for ksz, blur in ((3, None), (1, 3), (3, 3), (3, 4), (1, 4)):
+            m = fn(6, 10, ksz, blur)
+            with torch.no_grad():
+                for p in m.parameters():
+                    p.copy_(torch.randn_like(p) * 0.3)
+            x = torch.randn(2, 6, 8, 8, requires_grad=True)
+            y = m(x)
+            names = ["x"] + [k for k, _ in m.named_parameters()]
+            leaves = [x] + list(m.parameters())
+            g1 = torch.autograd.grad(y.square().sum(), leaves, create_graph=True)
+            g2 = torch.autograd.grad(g1[0].square().sum(), leaves, allow_unused=True)
+            out[f"{fn_name}_k{ksz}_b{blur}"] = {
+                "fn": fn_name, "kernel_size": ksz, "blur_size": blur,
+                "state": sd_of(m), "x": x.detach().clone(), "y": y.detach().clone(),
+                "grad": {n: g.detach().clone() for n, g in zip(names, g1)},
+                "grad2": {n: (None if g is None else g.detach().clone()) for n, g in zip(names, g2)},
+            }
+    save("resample_convs", out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
+    if len(sys.argv) > 1:  # regenerate only the named fixtures: python oracle/make_goldens.py resample_convs
+        for name in sys.argv[1:]:
+            globals()["gold_" + name]()
+        sys.exit(0)
     gold_modconv()
     gold_upfirdn2d()
     gold_small_ops()
@@ -420,3 +450,4 @@ if __name__ == "__main__":
     gold_generator()
     gold_dcgan()
     gold_trajectory()
+    gold_resample_convs()

@@ -365,27 +365,12 @@ def test_loss_match_100_steps_vs_oracle(dev):
           f"worst rel L2 update diff D {worst['ud']:.2e} G {worst['ug']:.2e}")
     assert worst["d"] < 1e-4 and worst["g"] < 1e-4, worst
     assert worst["ud"] < 5e-2 and worst["ug"] < 5e-2, worst
-
-
-def test_train_step_bf16_runs_and_tracks_fp32(dev):
-    """README recipe flags (bf16 autocast + channels_last): first-step losses within bf16 tolerance of fp32."""
-    from oracle import gan_oracle as O
-    from oracle.detparams import det_state, det_uniform
-    from oracle.tape import RandTape
-
-    size, batch = 32, 8
-    g_state = det_state(O.stylegan2_generator_shapes(size, base_dim=64), seed=7, bias_amp=0.0, scale_amp=0.05)
-    d_state = det_state(O.stylegan2_discriminator_shapes(size, base_dim=16), seed=8, bias_amp=0.0, scale_amp=0.5)
-    reals = (det_uniform((batch, 3, size, size), 77) * 2.0).to(dev)
-    tr32 = _trainer16(dev, g_state, d_state, mixed=False, gen_base=64, size=size, batch=batch)
-    with RandTape() as rec:
-        l32 = tr32.train_step(lambda: reals.clone())
-    trbf = _trainer16(dev, g_state, d_state, mixed=True, gen_base=64, size=size, batch=batch)
-    with RandTape(rec.tape):
-        lbf = trbf.train_step(lambda: reals.clone())
-    for k in ("loss/d", "loss/g"):
-        a, b = float(lbf[k]), float(l32[k])
-        assert math.isfinite(a) and abs(a - b) <= 3e-2 * max(1.0, abs(b)), (k, a, b)
+    # EMA (utils.py:84-96; warmup 10: copy at the 10th step, 90 lerps after): the HIP trainer averaged its own
+    # post-step generator weights, the oracle its own -- they differ by the update differences bounded above
+    # (<= 5e-2 of a 2e-4 Adam step), so the two averages agree to ~1e-5 absolute
+    assert counter == steps and int(tr.gen_ema.counter) == steps
+    for (k, v), ref in zip(tr.gen_ema.ema_model.state_dict().items(), ema):
+        assert float((v.detach().cpu() - ref).abs().max()) < 5e-5, k
 
 
 def test_bucket_allreduce_on_rccl_single_rank(dev, monkeypatch):

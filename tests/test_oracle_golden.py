@@ -263,3 +263,26 @@ def test_trajectory16(golden):
     for (k, ref), e in zip(g["final"]["ema"].items(), ema):
         got = projections(e)
         assert float((got - ref).abs().max()) < 1e-4 * max(float(ref[1]), 1e-3), k
+
+
+def test_resample_convs(golden):
+    """up_conv_blur / blur_conv_down (nvidia_ops.py:81-123), every branch, against the reference's outputs."""
+    for tag, g in golden("resample_convs").items():
+        fn = getattr(O, g["fn"])
+        sd = {k: v.clone().requires_grad_(v.is_floating_point() and not k.endswith("kernel")) for k, v in g["state"].items()}
+        x = g["x"].clone().requires_grad_(True)
+        y = fn(sd, x, g["kernel_size"], g["blur_size"])
+        assert y.shape == g["y"].shape, tag
+        assert rel_err(y, g["y"]) < 1e-5, tag
+        names = list(g["grad"].keys())
+        leaves = [x] + [sd[n] for n in names[1:]]
+        g1 = torch.autograd.grad(y.square().sum(), leaves, create_graph=True)
+        for n, t in zip(names, g1):
+            assert rel_err(t, g["grad"][n]) < 1e-5, (tag, n)
+        g2 = torch.autograd.grad(g1[0].square().sum(), leaves, allow_unused=True)
+        for n, t in zip(names, g2):
+            ref = g["grad2"][n]
+            if ref is None:
+                assert t is None or float(t.abs().max()) == 0.0, (tag, n)
+            else:
+                assert rel_err(t, ref) < 1e-4, (tag, n)
