@@ -21,6 +21,7 @@ from . import functional as GF
 from .distributed import GradBucketReducer, all_reduce_sum, broadcast, init_from_env, interleaved_shard
 from .losses import get_loss, get_regularizer
 from .modelling import build_discriminator, build_generator
+from .optim import make_optimizer
 from .utils import EMA, make_parser, prepare_model
 
 
@@ -87,15 +88,13 @@ class Trainer:
         self.gen_ema = EMA(self.gen)
         self.criterion = get_loss(cfg.method)
         self.regularizer = get_regularizer(cfg.regularizer)
-        optim_cls = getattr(torch.optim, cfg.optimizer)
         okw = _fix_betas(cfg.optimizer_kwargs)
-        if cfg.hip_graph and cfg.optimizer in ("Adam", "AdamW"):
-            okw = dict(okw, capturable=True)  # step counters live on the device: the optimizer step can be captured
         self._graph = None
         self._graph_reals: List[Tensor] = []
         self._graph_logs: Optional[Dict[str, Tensor]] = None
-        self.optim_d = optim_cls(self.disc.parameters(), cfg.lr, **okw)
-        self.optim_g = optim_cls(self.gen.parameters(), cfg.lr, **okw)
+        # train_celeba.py:75-77: any torch.optim class by name; Adam / AdamW run as one kernel over the flat arenas
+        self.optim_d = make_optimizer(cfg.optimizer, self.disc, cfg.lr, okw, capturable=cfg.hip_graph)
+        self.optim_g = make_optimizer(cfg.optimizer, self.gen, cfg.lr, okw, capturable=cfg.hip_graph)
         self.autocast_ctx = lambda: torch.autocast(self.device.type, dtype=torch.bfloat16, enabled=cfg.mixed_precision)
         self.step = 0
 

@@ -216,6 +216,17 @@ int gan_mbstd_bwd(const void* x, const float* gstat, void* gx, int N, int G, int
  * ema[i] += (p[i] - ema[i]) * weight over one flat fp32 arena. */
 int gan_ema_lerp(float* ema, const float* p, int64_t n, float weight, gan_stream_t stream);
 
+/* ---- Adam -------------------------------------------------------------------------------
+ * replaces torch.optim.Adam / AdamW as built at train_celeba.py:75-77 (one launch per parameter tensor and scalar
+ * there) by one pass over flat arenas: p, g (gradient), m (exp_avg), v (exp_avg_sq): fp32 [n], 16-byte aligned.
+ *   t = step[0] (+ 1 first when advance != 0: the count lives on the device so the call can be graph-captured)
+ *   g' = g + weight_decay * p (decoupled = 0)      or      p *= 1 - lr * weight_decay (decoupled = 1, AdamW)
+ *   m += (g' - m) * (1 - beta1);  v = v * beta2 + g'^2 * (1 - beta2)
+ *   p -= lr / (1 - beta1^t) * m / (sqrt(v) / sqrt(1 - beta2^t) + eps)
+ * advance = 0 lets one logical step be issued as several calls over sub-ranges of the arena. */
+int gan_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float* step, int advance, float lr, float beta1,
+                  float beta2, float eps, float weight_decay, int decoupled, gan_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
