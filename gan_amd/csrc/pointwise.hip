@@ -823,6 +823,157 @@ extern "C" int gan_mbstd_bwd(const void* x, const float* gstat, void* gx, int N,
     return GAN_OK;
 }
 
+// Second order (R1 differentiates the statistic twice, losses.py:100-103): with B(x, gstat) the backward above and u
+// the cotangent of its output gx, per group column j and element e, over the G members k
+//   c = gstat[j] / (G E),  S = sum_k u_k d_k,  ubar = mean_k u_k,  d_k = x_k - mean,  sigma = sqrt(var + 1e-6)
+//   d<u, B> / d x_m      = c * ( (u_m - ubar) / sigma  -  S d_m / (G sigma^3) )
+//   d<u, B> / d gstat[j] = sum_e S / (G E sigma)
+// One workgroup per group column (deterministic block reduction: no atomics, nothing to zero).
+template <typename T>
+__global__ void __launch_bounds__(TPB) mbstd_bwd2_k(const T* __restrict__ x, const float* __restrict__ gstat, const T* __restrict__ u,
+                                                    T* __restrict__ gx2, float* __restrict__ ggstat, int M, int G, int64_t E) {
+    __shared__ float red[TPB / 64];
+    const int j = blockIdx.x;
+    const float invG = 1.f / (float)G;
+    const float c = gstat[j] * invG / (float)E;
+    float acc = 0.f;
+    for (int64_t e = threadIdx.x; e < E; e += TPB) {
+        float mean = 0.f, ubar = 0.f;
+        for (int k = 0; k < G; ++k) {
+            const int64_t o = ((int64_t)(j + k * M)) * E + e;
+            mean += (float)x[o];
+            ubar += (float)u[o];
+        }
+        mean *= invG;
+        ubar *= invG;
+        float var = 0.f, S = 0.f;
+        for (int k = 0; k < G; ++k) {
+            const int64_t o = ((int64_t)(j + k * M)) * E + e;
+            const float d = (float)x[o] - mean;
+            var = fmaf(d, d, var);
+            S = fmaf((float)u[o], d, S);
+        }
+        const float sigma = sqrtf(var * invG + 1e-6f);
+        const float is = 1.f / sigma;
+        acc = fmaf(S, is, acc);
+        if (gx2) {
+            const float a = c * is, b = c * S * invG * is * is * is;
+            for (int k = 0; k < G; ++k) {
+                const int64_t o = ((int64_t)(j + k * M)) * E + e;
+                gx2[o] = (T)(a * ((float)u[o] - ubar) - b * ((float)x[o] - mean));
+            }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0 && ggstat) {
+        float t = 0.f;
+        for (int w = 0; w < TPB / 64; ++w) t += red[w];
+        ggstat[j] = t * invG / (float)E;
+    }
+}
+
+extern "C" int gan_mbstd_bwd2(const void* x, const float* gstat, const void* u, void* gx2, float* ggstat, int N, int G, int64_t HW,
+                              int C, int dtype, gan_stream_t stream) {
+    GAN_CHECK_ARG(x && gstat && u && (gx2 || ggstat), "mbstd_bwd2: null pointer");
+    GAN_CHECK_ARG(G >= 1 && N > 0 && N % G == 0, "mbstd_bwd2: batch %d is not a multiple of group size %d", N, G);
+    GAN_CHECK_ARG(HW > 0 && C > 0, "mbstd_bwd2: bad shape");
+    GAN_CHECK_ARG(dtype == GAN_F32 || dtype == GAN_BF16, "mbstd_bwd2: bad dtype %d", dtype);
+    hipStream_t st = (hipStream_t)stream;
+    const int M = N / G;
+    if (dtype == GAN_F32)
+        hipLaunchKernelGGL((mbstd_bwd2_k<float>), dim3(M), dim3(TPB), 0, st, (const float*)x, gstat, (const float*)u, (float*)gx2, ggstat, M, G, HW * C);
+    else
+        hipLaunchKernelGGL((mbstd_bwd2_k<bf16>), dim3(M), dim3(TPB), 0, st, (const bf16*)x, gstat, (const bf16*)u, (bf16*)gx2, ggstat, M, G, HW * C);
+    GAN_CHECK_LAUNCH("mbstd_bwd2");
+    return GAN_OK;
+}
+
+// MinibatchStdDev's output tensor (progressive_gan.py:31-36: the statistic repeated over the group, expanded to a
+// plane and concatenated as channel C): out[n][hw][c] = x[n][hw][c] for c < C, stat[n % M] for c == C, in one pass
+// (the reference's repeat / view / expand / cat are five launches).  And its adjoint: gx = g[..., :C],
+// gstat[j] = sum_k sum_hw g[j + k*M][hw][C].  Both maps are linear, each is the other's adjoint.
+template <typename T>
+__global__ void __launch_bounds__(TPB) mbstd_concat_k(const T* __restrict__ x, const float* __restrict__ stat, T* __restrict__ out,
+                                                      int64_t NP /* N*HW */, int64_t HW, int C, int M) {
+    const int Co = C + 1;
+    const int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (i >= NP * Co) return;
+    const int64_t pix = i / Co;
+    const int c = (int)(i - pix * Co);
+    out[i] = c < C ? x[pix * C + c] : (T)stat[(pix / HW) % M];
+}
+
+template <typename T>
+__global__ void __launch_bounds__(TPB) mbstd_concat_adj_k(const T* __restrict__ g, T* __restrict__ gx, float* __restrict__ gstat,
+                                                          int64_t NP, int64_t HW, int C, int M, int G, unsigned copy_blocks) {
+    const int Co = C + 1;
+    if (blockIdx.x < copy_blocks) {
+        const int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x;
+        if (gx == nullptr || i >= NP * C) return;
+        const int64_t pix = i / C;
+        gx[i] = g[pix * Co + (i - pix * C)];
+        return;
+    }
+    // one block per group column j: sum of the plane channel over the G members' pixels
+    __shared__ float red[TPB / 64];
+    const int j = blockIdx.x - copy_blocks;
+    float acc = 0.f;
+    for (int64_t e = threadIdx.x; e < (int64_t)G * HW; e += TPB) {
+        const int k = (int)(e / HW);
+        const int64_t hw = e - (int64_t)k * HW;
+        acc += (float)g[(((int64_t)(j + k * M)) * HW + hw) * Co + C];
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int w = 0; w < TPB / 64; ++w) t += red[w];
+        gstat[j] = t;
+    }
+}
+
+extern "C" int gan_mbstd_concat(const void* x, const float* stat, void* out, int N, int G, int64_t HW, int C, int dtype,
+                                gan_stream_t stream) {
+    GAN_CHECK_ARG(x && stat && out, "mbstd_concat: null pointer");
+    GAN_CHECK_ARG(G >= 1 && N > 0 && N % G == 0, "mbstd_concat: batch %d is not a multiple of group size %d", N, G);
+    GAN_CHECK_ARG(HW > 0 && C > 0, "mbstd_concat: bad shape");
+    GAN_CHECK_ARG(dtype == GAN_F32 || dtype == GAN_BF16, "mbstd_concat: bad dtype %d", dtype);
+    const int64_t NP = (int64_t)N * HW, total = NP * (C + 1);
+    const int64_t blocks = ceil_div64(total, TPB);
+    GAN_CHECK_ARG(blocks < (1LL << 31), "mbstd_concat: too large for the grid");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == GAN_F32)
+        hipLaunchKernelGGL((mbstd_concat_k<float>), dim3((unsigned)blocks), dim3(TPB), 0, st, (const float*)x, stat, (float*)out, NP, HW, C, N / G);
+    else
+        hipLaunchKernelGGL((mbstd_concat_k<bf16>), dim3((unsigned)blocks), dim3(TPB), 0, st, (const bf16*)x, stat, (bf16*)out, NP, HW, C, N / G);
+    GAN_CHECK_LAUNCH("mbstd_concat");
+    return GAN_OK;
+}
+
+extern "C" int gan_mbstd_concat_adj(const void* g, void* gx, float* gstat, int N, int G, int64_t HW, int C, int dtype,
+                                    gan_stream_t stream) {
+    GAN_CHECK_ARG(g && gstat, "mbstd_concat_adj: null pointer");
+    GAN_CHECK_ARG(G >= 1 && N > 0 && N % G == 0, "mbstd_concat_adj: batch %d is not a multiple of group size %d", N, G);
+    GAN_CHECK_ARG(HW > 0 && C > 0, "mbstd_concat_adj: bad shape");
+    GAN_CHECK_ARG(dtype == GAN_F32 || dtype == GAN_BF16, "mbstd_concat_adj: bad dtype %d", dtype);
+    const int64_t NP = (int64_t)N * HW;
+    const int M = N / G;
+    const int64_t copy_blocks = gx ? ceil_div64(NP * C, TPB) : 0;
+    GAN_CHECK_ARG(copy_blocks + M < (1LL << 31), "mbstd_concat_adj: too large for the grid");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == GAN_F32)
+        hipLaunchKernelGGL((mbstd_concat_adj_k<float>), dim3((unsigned)(copy_blocks + M)), dim3(TPB), 0, st, (const float*)g, (float*)gx, gstat,
+                           NP, HW, C, M, G, (unsigned)copy_blocks);
+    else
+        hipLaunchKernelGGL((mbstd_concat_adj_k<bf16>), dim3((unsigned)(copy_blocks + M)), dim3(TPB), 0, st, (const bf16*)g, (bf16*)gx, gstat, NP,
+                           HW, C, M, G, (unsigned)copy_blocks);
+    GAN_CHECK_LAUNCH("mbstd_concat_adj");
+    return GAN_OK;
+}
+
 // =========================================================================================
 // EMA lerp over one flat fp32 arena (reference: utils.py:95-96)
 // =========================================================================================

@@ -816,24 +816,27 @@ class DBlockInputFn(Function):
     adding two full-resolution tensors.  Backward is composed of the Functions above (differentiable again)."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, ws, slope, pool_in_conv):
+    def forward(ctx, x, w1, b1, ws, slope, pool_in_conv, bs=None):
         pad = (w1.shape[2] - 1) // 2
         p1 = raw_conv2d(x, w1, pad, pad, bias=b1, in_slope=slope)
         if pool_in_conv:  # thin layers: conv1x1 -> pool in one launch (the same linear map)
             xs = None
-            s = raw_conv2d(x, ws, 0, 0, pool=True)
+            s = raw_conv2d(x, ws, 0, 0, pool=True, bias=bs)
         else:             # wide layers: the 1x1 GEMM on a quarter of the pixels
             xs = raw_upfirdn2d(x, _ones_taps(x, 0.25), 1, 2, 0, 0, x.shape[2] // 2, x.shape[3] // 2)
-            s = raw_conv2d(xs, ws, 0, 0)
+            s = raw_conv2d(xs, ws, 0, 0, bias=bs)
         ctx.save_for_backward(x, w1, b1, ws, xs)
         ctx.cfg = (pad, slope, pool_in_conv)
+        ctx.bs_meta = None if bs is None else (bs.shape, bs.dtype)
         return p1, s
 
     @staticmethod
     def backward(ctx, g_p1, g_s):
         x, w1, b1, ws, xs = ctx.saved_tensors
         pad, slope, pool_in_conv = ctx.cfg
-        gx = gw1 = gb1 = gws = None
+        gx = gw1 = gb1 = gws = gbs = None
+        if ctx.bs_meta is not None and _need(ctx, 6):
+            gbs = ChanSumFn.apply(g_s, False).reshape(ctx.bs_meta[0]).to(ctx.bs_meta[1])
         if _need(ctx, 0):
             if pool_in_conv:
                 gx_s = Conv2dDgradFn.apply(g_s, ws, 0, 0, None, 1.0, True)
@@ -849,7 +852,7 @@ class DBlockInputFn(Function):
                 gws = Conv2dWgradFn.apply(x, g_s, 1, 1, 0, 0, 1.0, True).to(ws.dtype)
             else:
                 gws = Conv2dWgradFn.apply(xs, g_s, 1, 1, 0, 0).to(ws.dtype)
-        return gx, gw1, gb1, gws, None, None
+        return gx, gw1, gb1, gws, None, None, gbs
 
 
 class Conv2dWgradFn(Function):
@@ -996,30 +999,32 @@ class ConvBiasActFn(Function):
     Backward = mask_mul -> dgrad / wgrad / channel sum, all differentiable again."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, pad, slope, in_slope=1.0):
-        y = raw_conv2d(x, weight, pad, pad, bias=bias, slope=slope, in_slope=in_slope)
+    def forward(ctx, x, weight, bias, pad, slope, in_slope=1.0, pool=False):
+        y = raw_conv2d(x, weight, pad, pad, bias=bias, slope=slope, in_slope=in_slope, pool=pool)
         ctx.save_for_backward(x, weight, bias, y if slope != 1.0 else None)
-        ctx.cfg = (pad, slope, in_slope)
+        ctx.cfg = (pad, slope, in_slope, pool)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         x, weight, bias, y = ctx.saved_tensors
-        pad, slope, in_slope = ctx.cfg
+        pad, slope, in_slope, pool = ctx.cfg
         gz = MaskMulFn.apply(gy, y, slope) if slope != 1.0 else gy
         xaux = x if in_slope != 1.0 else None
-        gx = Conv2dDgradFn.apply(gz, weight, pad, pad, xaux, in_slope, False) if _need(ctx, 0) else None
+        gx = Conv2dDgradFn.apply(gz, weight, pad, pad, xaux, in_slope, pool) if _need(ctx, 0) else None
         gw = None
         if _need(ctx, 1):
-            gw = Conv2dWgradFn.apply(x, gz, weight.shape[2], weight.shape[3], pad, pad, in_slope, False).to(weight.dtype)
+            gw = Conv2dWgradFn.apply(x, gz, weight.shape[2], weight.shape[3], pad, pad, in_slope, pool).to(weight.dtype)
         gb = None
         if bias is not None and _need(ctx, 2):
             gb = ChanSumFn.apply(gz, False).reshape(bias.shape).to(bias.dtype)
-        return gx, gw, gb, None, None, None
+        return gx, gw, gb, None, None, None, None
 
 
-def conv_bias_act(x: Tensor, weight: Tensor, bias: Optional[Tensor], padding: int, slope: float = 1.0, in_slope: float = 1.0) -> Tensor:
-    return ConvBiasActFn.apply(x, weight, bias, padding, slope, in_slope)
+def conv_bias_act(x: Tensor, weight: Tensor, bias: Optional[Tensor], padding: int, slope: float = 1.0, in_slope: float = 1.0,
+                  pool: bool = False) -> Tensor:
+    """pool: AvgPool2d(2) of the convolution result, BEFORE the bias and the activation (avg_pool(z + b) = avg_pool(z) + b)."""
+    return ConvBiasActFn.apply(x, weight, bias, padding, slope, in_slope, pool)
 
 
 class DemodFn(Function):
@@ -1066,19 +1071,10 @@ class DemodFn(Function):
         return (gs.to(s.dtype) if gs is not None else None), (gw.to(weight.dtype) if gw is not None else None)
 
 
-def _mbstd_stat_ops(x: Tensor, group: int) -> Tensor:
-    n, c, h, w = x.shape
-    xf = x.float().reshape(group, n // group, c, h, w)
-    dev = xf - xf.mean(dim=0, keepdim=True)
-    std = (dev.square().sum(dim=0) / group + 1e-6).sqrt()
-    return std.mean(dim=(1, 2, 3))
-
-
 class MbstdFn(Function):
-    """(N/G,) fp32 statistic of MinibatchStdDev (progressive_gan.py:25-36): kernel gan_mbstd_fwd forward,
-    gan_mbstd_bwd backward.  Under create_graph (R1 differentiates it to second order) the backward is the
-    same formula written with fp32 tensor ops on this small tensor (N x 512 x 4 x 4), so it can be
-    differentiated again."""
+    """(N/G,) fp32 statistic of MinibatchStdDev (progressive_gan.py:25-36): kernel gan_mbstd_fwd; the backward is
+    MbstdBwdFn (kernel gan_mbstd_bwd), itself differentiable by kernel gan_mbstd_bwd2 -- R1 differentiates the
+    discriminator twice (losses.py:100-103), and every node of that graph is a HIP kernel."""
 
     @staticmethod
     def forward(ctx, x, group):
@@ -1089,23 +1085,94 @@ class MbstdFn(Function):
     @staticmethod
     def backward(ctx, gstat):
         (x,) = ctx.saved_tensors
-        group = ctx.group
-        if torch.is_grad_enabled():
-            # d stat_j / d x_k = dev_k / (G * std * E)  (sum_k dev_k = 0), as tensor ops on x and gstat.  Not a nested
-            # autograd.grad: a re-entrant backward leaves the capturing thread and aborts a HIP-graph capture.
-            n, c, h, w = x.shape
-            xf = x.float().reshape(group, n // group, c, h, w)
-            dev = xf - xf.mean(dim=0, keepdim=True)
-            std = (dev.square().sum(dim=0) / group + 1e-6).sqrt()
-            gx = gstat.float().reshape(1, n // group, 1, 1, 1) * dev / (std * float(group * c * h * w))
-            return gx.reshape(n, c, h, w).to(x.dtype), None
+        return MbstdBwdFn.apply(x, gstat, ctx.group), None
+
+
+class MbstdBwdFn(Function):
+    """gx[j + k*M] = gstat[j] * (x_k - mean_k x) / (G * std * C*H*W): the adjoint of the statistic in x, as a function
+    of (x, gstat).  Its own adjoint (both arguments) is one launch of gan_mbstd_bwd2."""
+
+    @staticmethod
+    def forward(ctx, x, gstat, group):
+        require_gpu(x, gstat)
         lib = _lib.load()
         xc = as_cl(x.detach())
         n, c, h, w = xc.shape
         g32 = _f32(gstat)
         gx = torch.empty_like(xc)
         check(lib.gan_mbstd_bwd(ptr(xc), ptr(g32), ptr(gx), n, group, h * w, c, dtype_code(xc), stream_of(xc)), "gan_mbstd_bwd")
-        return gx, None
+        ctx.save_for_backward(xc, g32)
+        ctx.group = group
+        ctx.gstat_dtype = gstat.dtype
+        return gx
+
+    @staticmethod
+    def backward(ctx, u):
+        xc, g32 = ctx.saved_tensors
+        group = ctx.group
+        if torch.is_grad_enabled():
+            # no caller: R1 / WGAN-GP (losses.py:89-103) stop at second order
+            raise _lib.GanAmdError("MinibatchStdDev: derivatives beyond second order are not implemented")
+        lib = _lib.load()
+        n, c, h, w = xc.shape
+        uc = as_cl(u.detach().to(xc.dtype))
+        gx2 = torch.empty_like(xc) if _need(ctx, 0) else None
+        ggstat = torch.empty((n // group,), dtype=torch.float32, device=xc.device) if _need(ctx, 1) else None
+        if gx2 is None and ggstat is None:
+            return None, None, None
+        check(lib.gan_mbstd_bwd2(ptr(xc), ptr(g32), ptr(uc), ptr(gx2), ptr(ggstat), n, group, h * w, c, dtype_code(xc), stream_of(xc)),
+              "gan_mbstd_bwd2")
+        return gx2, (ggstat.to(ctx.gstat_dtype) if ggstat is not None else None), None
+
+
+class MbstdConcatFn(Function):
+    """(x (N, C, H, W), stat (N/G,)) -> (N, C+1, H, W): the statistic of each sample's group column appended as a
+    constant plane (progressive_gan.py:31-36), one launch.  Linear in both arguments; its adjoint is
+    MbstdConcatAdjFn and vice versa, so the pair is closed under differentiation."""
+
+    @staticmethod
+    def forward(ctx, x, stat, group):
+        require_gpu(x, stat)
+        xc = as_cl(x.detach())
+        n, c, h, w = xc.shape
+        s32 = _f32(stat)
+        out = _empty_like_cl(xc, (n, c + 1, h, w))
+        check(_lib.load().gan_mbstd_concat(ptr(xc), ptr(s32), ptr(out), n, group, h * w, c, dtype_code(xc), stream_of(xc)), "gan_mbstd_concat")
+        ctx.group = group
+        ctx.meta = (x.dtype, stat.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        gx, gstat = MbstdConcatAdjFn.apply(g, ctx.group)
+        return (gx.to(ctx.meta[0]) if _need(ctx, 0) else None), (gstat.to(ctx.meta[1]) if _need(ctx, 1) else None), None
+
+
+class MbstdConcatAdjFn(Function):
+    """g (N, C+1, H, W) -> (g[:, :C], sum of the plane channel over each group column's members and pixels)."""
+
+    @staticmethod
+    def forward(ctx, g, group):
+        require_gpu(g)
+        gc = as_cl(g.detach())
+        n, co, h, w = gc.shape
+        gx = _empty_like_cl(gc, (n, co - 1, h, w))
+        gstat = torch.empty((n // group,), dtype=torch.float32, device=gc.device)
+        check(_lib.load().gan_mbstd_concat_adj(ptr(gc), ptr(gx), ptr(gstat), n, group, h * w, co - 1, dtype_code(gc), stream_of(gc)),
+              "gan_mbstd_concat_adj")
+        ctx.group = group
+        ctx.dtype = g.dtype
+        return gx, gstat
+
+    @staticmethod
+    def backward(ctx, ggx, ggstat):
+        return MbstdConcatFn.apply(ggx, ggstat, ctx.group).to(ctx.dtype), None
+
+
+def minibatch_stddev(x: Tensor, group: int) -> Tensor:
+    """MinibatchStdDev.forward (progressive_gan.py:25-36): (N, C, H, W) -> (N, C+1, H, W), two launches."""
+    stat = minibatch_stddev_stat(x, group)
+    return MbstdConcatFn.apply(x, stat, group)
 
 
 def minibatch_stddev_stat(x: Tensor, group: int) -> Tensor:

@@ -9,9 +9,9 @@ Fusions per block (progressive_gan.py:43-54):  each LeakyReLU is applied by the 
 consumes it while it stages its input, AvgPool2d(2) is applied to the MFMA accumulators of the
 convolution that precedes it (the shortcut's pool -> 1x1 conv runs as conv -> pool, the same linear
 map), and the adjoints of both ride in the input-/weight-gradient kernels; conv biases that precede
-AvgPool2d are added after it (avg_pool(z + b) = avg_pool(z) + b) and folded, together with the
-shortcut's bias and the per-channel `scale`, into the single residual pass
-    out = shortcut_conv + pooled * scale + (b_short + b2 * scale).
+AvgPool2d are added after it (avg_pool(z + b) = avg_pool(z) + b) on the same accumulators; the residual
+    out = shortcut + layers * scale
+is one pass.
 LeakyReLU is applied out of place (the shipped inplace=True breaks autograd).
 """
 from __future__ import annotations
@@ -37,9 +37,7 @@ class MinibatchStdDev(nn.Module):
         n, c, h, w = imgs.shape
         if n % self.group_size != 0:
             raise GF._lib.GanAmdError(f"MinibatchStdDev: batch {n} is not a multiple of group_size {self.group_size}")
-        stat = GF.minibatch_stddev_stat(imgs, self.group_size)  # (N/G,) fp32
-        plane = stat.repeat(self.group_size).to(imgs.dtype).view(n, 1, 1, 1).expand(n, 1, h, w)
-        return torch.cat([imgs, plane], dim=1).contiguous(memory_format=torch.channels_last)
+        return GF.minibatch_stddev(imgs, self.group_size)  # statistic + the appended plane: two launches
 
 
 class ProgressiveGanDiscriminatorBlock(nn.Module):
@@ -61,12 +59,11 @@ class ProgressiveGanDiscriminatorBlock(nn.Module):
         conv_s = self.shortcut[1]
         # act -> conv1 (+bias) and the shortcut (pool -> conv_s; for thin layers conv_s -> pool, the same linear
         # map, in one launch) share x: one autograd node, so their input gradients come out of one kernel
-        h, s = GF.DBlockInputFn.apply(x, conv1.weight, conv1.bias, conv_s.weight, act0.negative_slope, conv_s.out_channels <= 64)
-        # act -> conv2 -> pool in one launch
-        h = GF.Conv2dFn.apply(h, conv2.weight, conv2.padding[0], conv2.padding[1], act1.negative_slope, True)
-        scale = self.scale.reshape(-1)
-        bias = conv_s.bias + conv2.bias * scale  # (Cout,) -- three tiny vectors
-        return GF.affine_act(h, a=scale, b=bias, r=s)
+        h, s = GF.DBlockInputFn.apply(x, conv1.weight, conv1.bias, conv_s.weight, act0.negative_slope, conv_s.out_channels <= 64,
+                                      conv_s.bias)
+        # act -> conv2 -> pool (+ bias: avg_pool(z + b) = avg_pool(z) + b) in one launch
+        h = GF.conv_bias_act(h, conv2.weight, conv2.bias, conv2.padding[0], 1.0, act1.negative_slope, True)
+        return GF.affine_act(h, a=self.scale.reshape(-1), r=s)  # shortcut + layers * scale (progressive_gan.py:54)
 
 
 class ProgressiveGanDiscriminator(nn.Sequential):

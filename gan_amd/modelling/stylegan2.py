@@ -31,6 +31,25 @@ from .progressive_gan import init_weights
 from .stylegan import Noise
 
 
+def batched_conv2d(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, stride: int = 1, padding: int = 0) -> Tensor:
+    """The reference's `batched_conv2d = torch.vmap(F.conv2d)` (stylegan2.py:18): one convolution per sample with that
+    sample's own weights -- x (N, Cin, H, W), weight (N, Cout, Cin, kh, kw), bias (N, Cout) or None.  Kept for API
+    parity: ModulatedConv2d below never forms per-sample weights (module docstring), so this entry is off the hot
+    path and simply runs the shared-weight implicit-GEMM kernel once per sample; differentiable to any order in x,
+    weight and bias (Conv2dFn)."""
+    if stride not in (1, (1, 1)):
+        raise GF._lib.GanAmdError("batched_conv2d supports stride 1")
+    if x.dim() != 4 or weight.dim() != 5 or weight.shape[0] != x.shape[0]:
+        raise GF._lib.GanAmdError(f"batched_conv2d: x {tuple(x.shape)} and weight {tuple(weight.shape)} do not pair up per sample")
+    py, px = (padding, padding) if isinstance(padding, int) else padding
+    x = to_act(x)
+    ys = [GF.Conv2dFn.apply(x[n:n + 1], weight[n], py, px) for n in range(x.shape[0])]
+    y = torch.cat(ys, dim=0)
+    if bias is not None:
+        y = y + bias.to(y.dtype).view(x.shape[0], -1, 1, 1)
+    return y
+
+
 class ModConvFn(Function):
     """y = lrelu_slope( dinv * conv(U(x) * s, W) + b + noise * ns ),  U = nearest x2 if up2.
 

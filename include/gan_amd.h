@@ -211,6 +211,18 @@ int gan_mbstd_fwd(const void* x, float* stat, int N, int G, int64_t HW, int C, i
 int gan_mbstd_bwd(const void* x, const float* gstat, void* gx, int N, int G, int64_t HW, int C, int dtype,
                   gan_stream_t stream);
 
+/* autograd of gan_mbstd_bwd (second order of the statistic: R1 differentiates the discriminator twice,
+ * losses.py:100-103).  u: cotangent of gx, shaped like x.  Outputs (either may be NULL):
+ *   gx2 [N][HW][C] (x's dtype) = d<u, gx>/dx,   ggstat fp32 [M] = d<u, gx>/dgstat (every element written). */
+int gan_mbstd_bwd2(const void* x, const float* gstat, const void* u, void* gx2, float* ggstat, int N, int G, int64_t HW, int C,
+                   int dtype, gan_stream_t stream);
+
+/* The module's output (progressive_gan.py:31-36): out [N][HW][C+1] = x with the statistic of the sample's group column
+ * (stat[n % M], fp32 [M]) appended as channel C -- the reference's repeat / view / expand / cat in one pass -- and the
+ * adjoint of that linear map: gx [N][HW][C] = g[..., :C] (NULL: skipped), gstat[j] = sum_k sum_hw g[j + k*M][hw][C]. */
+int gan_mbstd_concat(const void* x, const float* stat, void* out, int N, int G, int64_t HW, int C, int dtype, gan_stream_t stream);
+int gan_mbstd_concat_adj(const void* g, void* gx, float* gstat, int N, int G, int64_t HW, int C, int dtype, gan_stream_t stream);
+
 /* ---- EMA ---------------------------------------------------------------------------------
  * replaces the per-parameter lerp_ loop of EMA.step   utils.py:95-96
  * ema[i] += (p[i] - ema[i]) * weight over one flat fp32 arena. */

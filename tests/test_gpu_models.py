@@ -73,6 +73,27 @@ def test_modulated_conv_golden(dev, golden, tag, k, demod):
             assert rel_err(t, ref) < TOL2, (n, rel_err(t, ref))
 
 
+def test_batched_conv2d_golden(dev, golden):
+    """`batched_conv2d` (stylegan2.py:18, vmap(F.conv2d)) fed the per-sample weights exactly as the reference's
+    ModulatedConv2d.forward builds them (stylegan2.py:30-36) must reproduce the reference module's output, and its
+    gradient with respect to x."""
+    import torch.nn.functional as F
+
+    from gan_amd.modelling.stylegan2 import batched_conv2d
+
+    g = golden("modconv")["k3_demod"]
+    st = {k: v.to(dev) for k, v in g["state"].items()}
+    x = g["x"].to(dev).requires_grad_(True)
+    w = g["w"].to(dev)
+    style = F.linear(w, st["style_weight.weight"], st["style_weight.bias"]) + 1
+    wmod = st["weight"].unsqueeze(0) * style.view(-1, 1, style.shape[1], 1, 1)
+    wmod = F.normalize(wmod, dim=(2, 3, 4), eps=1e-8)
+    y = batched_conv2d(x, wmod, st["bias"].expand(x.shape[0], -1), padding=1)
+    assert rel_err(y, g["y"]) < TOL
+    (gx,) = torch.autograd.grad(y.square().sum(), x)
+    assert rel_err(gx, g["grad"]["x"]) < TOL
+
+
 def test_modulated_conv_bf16_autocast(dev, golden):
     """Under bf16 autocast the kernel computes in bf16 with fp32 accumulation; tolerance 1e-2 against the
     fp32 reference output (the reference's ModulatedConv2d returns fp32 under autocast)."""

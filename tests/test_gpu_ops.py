@@ -671,15 +671,25 @@ def test_mbstd_backward_kernel(dev, shape, dtype):
     (gr,) = torch.autograd.grad((want * coef.double().cpu()).sum(), xr, create_graph=True)
     tol = TOL32 if dtype == torch.float32 else TOLBF
     assert rel_err(gx, gr) < tol
-    if dtype == torch.float32:
+    # second order on the kernels: MbstdBwdFn (gan_mbstd_bwd) differentiated by gan_mbstd_bwd2, with respect to x and to
+    # the incoming gradient of the statistic (here through `coef`)
+    coef_g = coef.clone().requires_grad_(True)
+    coef_r = coef.double().cpu().requires_grad_(True)
+    stat = GF.minibatch_stddev_stat(x, group)
+    (g1,) = torch.autograd.grad((stat * coef_g).sum(), x, create_graph=True)
+    (gr,) = torch.autograd.grad((ref_stat(xr) * coef_r).sum(), xr, create_graph=True)
+    assert rel_err(g1, gr) < tol
+    wgt = torch.randn(n, c, h, w, generator=g)
+    g2, g2c = torch.autograd.grad((g1.float() * wgt.to(dev)).sum() * 1e3, [x, coef_g])
+    g2r, g2cr = torch.autograd.grad((gr * wgt.double()).sum() * 1e3, [xr, coef_r])
+    # the second derivative carries 1/std^3: elements whose group variance is tiny make it ill-conditioned in fp32
+    # (the reference formula in plain fp32 tensor ops is itself 1.2e-3 off its fp64 evaluation on this data)
+    assert rel_err(g2, g2r) < (5e-3 if dtype == torch.float32 else 3e-2), rel_err(g2, g2r)
+    assert rel_err(g2c, g2cr) < (1e-4 if dtype == torch.float32 else 2e-2), rel_err(g2c, g2cr)
+    with pytest.raises(Exception):  # third order: not implemented, and says so
         stat = GF.minibatch_stddev_stat(x, group)
-        (g1,) = torch.autograd.grad((stat * coef).sum(), x, create_graph=True)  # differentiable path
-        assert rel_err(g1, gr) < TOL32
-        (g2,) = torch.autograd.grad(g1.square().sum(), x)
-        (g2r,) = torch.autograd.grad(gr.square().sum(), xr)
-        # the second derivative carries 1/std^3: elements whose group variance is tiny make it ill-conditioned in
-        # fp32 (the reference formula in plain fp32 tensor ops is itself 1.2e-3 off its fp64 evaluation on this data)
-        assert rel_err(g2, g2r) < 5e-3
+        (g1,) = torch.autograd.grad((stat * coef).sum(), x, create_graph=True)
+        torch.autograd.grad(g1.square().sum(), x, create_graph=True)
 
 
 @pytest.mark.parametrize("shape", [(32, 16, 3, 3), (16, 3, 1, 1), (1, 512, 4, 4), (24, 40, 3, 3)])
