@@ -248,7 +248,8 @@ def main():
         raise SystemExit("global batch must be a multiple of 4 * gpus (MinibatchStdDev groups)")
     torch.manual_seed(1234 + rank)
     cfg, trainer, micro = make_trainer(args, device, world)
-    next_reals = synthetic_reals(cfg, device, micro, seed=rank)
+    # one seed: every rank draws the same global batches and keeps its interleaved shard (MinibatchStdDev groups)
+    next_reals = synthetic_reals(cfg, device, micro, seed=0, rank=rank, world=world)
 
     def sync():
         torch.cuda.synchronize()

@@ -134,12 +134,24 @@ class Trainer:
         except StopIteration as stop:
             return stop.value
 
-    def _flat_allreduce(self, red: GradBucketReducer) -> None:
+    def _flat_allreduce(self, red: GradBucketReducer, async_op: bool = False):
+        """Mean of the whole gradient arena across ranks (one collective: 40 MB per network).  async_op: returns the
+        work handle (None where the backend completed it synchronously); the caller's stream is not made to wait."""
         if red.world > 1 or red._force:
-            import torch.distributed as dist
-
             red.arena.grad.div_(red.world)
-            all_reduce_sum(red.arena.grad, group=red.group)
+            return all_reduce_sum(red.arena.grad, group=red.group, async_op=async_op)
+        return None
+
+    def _exchange(self, action: str, red: GradBucketReducer) -> None:
+        """The gradient exchange the iteration asks for at a cut between two graph segments (see _iteration)."""
+        if action == "reduce":
+            self._flat_allreduce(red)
+        elif action == "start":
+            self._inflight = self._flat_allreduce(red, async_op=True)
+        elif action == "wait":
+            work, self._inflight = getattr(self, "_inflight", None), None
+            if work is not None:
+                work.wait()  # orders the current stream behind the collective; the host does not block
 
     # ---- HIP graphs ---------------------------------------------------------------------------------
     def _graph_step(self, next_reals: Callable[[], Tensor]) -> Dict[str, Tensor]:
@@ -154,33 +166,28 @@ class Trainer:
             feed = iter(self._graph_reals)
             # `.detach()`: an alias, so that requires_grad_ stays off the static buffer
             it = self._iteration(lambda: next(feed).detach(), overlap=False)
-            segments = []  # (graph, reducer whose arena is averaged after it | None)
+            segments = []  # (graph, (action, reducer) of the gradient exchange that follows it | None)
             pool = torch.cuda.graph_pool_handle()
             torch.cuda.synchronize()
             # With a process group up, RCCL's watchdog thread polls the events of outstanding collectives.  Under
             # the default "global" capture mode such a hipEventQuery from another thread is an error that takes the
             # process down (seen: "operation not permitted when stream is capturing" from ProcessGroupNCCL's
-            # watchdog).  Capture in thread-local mode, and let the watchdog retire what the eager iterations left.
+            # watchdog).  Capture in thread-local mode (rehearsed with and without a pause in front: not needed).
             import torch.distributed as dist
 
-            if dist.is_available() and dist.is_initialized():
-                import time
-
-                if os.environ.get("GAN_AMD_NO_CAPTURE_SLEEP") != "1":  # (test hook: thread-local mode alone must hold)
-                    time.sleep(0.3)
             done = False
             failed: Optional[BaseException] = None
             try:
                 while not done:
                     graph = torch.cuda.CUDAGraph()
-                    red = None
+                    cut = None
                     with torch.cuda.graph(graph, pool=pool, capture_error_mode="thread_local"):
                         try:
-                            red = next(it)
+                            cut = next(it)
                         except StopIteration as stop:
                             self._graph_logs = stop.value
                             done = True
-                    segments.append((graph, red))
+                    segments.append((graph, cut))
             except Exception as exc:  # capture refused (driver / allocator state): keep training, launched from the host
                 failed = exc
                 it.close()
@@ -212,19 +219,28 @@ class Trainer:
         else:
             for buf in self._graph_reals:
                 buf.copy_(next_reals())
-        for graph, red in self._graph:
+        for graph, cut in self._graph:
             graph.replay()
-            if red is not None:
-                self._flat_allreduce(red)
+            if cut is not None:
+                self._exchange(*cut)
         GF._PACK_CACHE.clear()  # a replay updates the weights without bumping their Python-side versions
         GF._PAD_MEMO.clear()
         return {k: v.clone() for k, v in self._graph_logs.items()}
 
     def _iteration(self, next_reals: Callable[[], Tensor], overlap: bool):
-        """The iteration as a generator: with overlap=False it yields the reducer whose gradient arena must be
-        averaged across ranks at that point (the cuts between the HIP graphs); with overlap=True the buckets
-        are reduced from hooks during the backward pass and nothing is yielded.  Returns the log dict."""
+        """The iteration as a generator.  overlap=True (host-launched): gradient buckets are all-reduced from hooks
+        while the backward pass runs, nothing is yielded.  overlap=False (HIP graphs): it yields (action, reducer) at
+        the points where gradients cross ranks -- the cuts between the graphs:
+            ("start", red_d)  after the discriminator's backward: its arena's all-reduce is launched asynchronously
+            ("wait", red_d)   after the generator's FORWARD of the G step, which does not depend on D and so runs
+                              under that collective (same random draws in the same order: only stream order moves)
+            ("reduce", red)   a plain blocking exchange (generator gradients; D with n_disc > 1 or grad_accum > 1).
+        Why not buckets under the backward here too: with R1 every D parameter's gradient has a first-order part
+        (produced head -> input) and a second-order part (produced input -> head), so no bucket is complete until
+        the backward is nearly over; and G's large tensors (512-channel blocks) are the LAST its backward reaches.
+        Returns the log dict."""
         cfg, disc, gen = self.cfg, self.disc, self.gen
+        early_g = None  # (zs, generator output) of the G step when its forward ran under D's all-reduce
         for i in range(cfg.n_disc):
             cached_reals: Optional[List[Tensor]] = [] if i == cfg.n_disc - 1 else None
             if cfg.method == "wgan" and cfg.regularizer == "none":
@@ -256,7 +272,14 @@ class Trainer:
                         self.red_d.finish()
                     else:
                         self.red_d.arena.gather_grads()
-                        yield self.red_d
+                        if i == cfg.n_disc - 1 and cfg.grad_accum == 1:
+                            yield ("start", self.red_d)
+                            zs = torch.randn(reals.shape[0], self.z_dim, device=self.device)
+                            with self.autocast_ctx():
+                                early_g = gen(zs)
+                            yield ("wait", self.red_d)
+                        else:
+                            yield ("reduce", self.red_d)
             self.optim_d.step()
             if overlap:
                 self.red_d.zero_grad()
@@ -264,9 +287,11 @@ class Trainer:
         disc.requires_grad_(False)
         try:
             for a in range(cfg.grad_accum):
-                zs = torch.randn(reals.shape[0], self.z_dim, device=self.device)
+                if early_g is None:
+                    zs = torch.randn(reals.shape[0], self.z_dim, device=self.device)
                 with self.autocast_ctx():
-                    loss_g = self.criterion.g_loss(disc(gen(zs)), lambda: disc(cached_reals[a]))
+                    g_out = gen(zs) if early_g is None else early_g
+                    loss_g = self.criterion.g_loss(disc(g_out), lambda: disc(cached_reals[a]))
                 last = a == cfg.grad_accum - 1
                 if last and overlap:
                     self.red_g.prepare()
@@ -279,7 +304,7 @@ class Trainer:
             disc.requires_grad_(True)
         if not overlap:
             self.red_g.arena.gather_grads()
-            yield self.red_g
+            yield ("reduce", self.red_g)
         self.optim_g.step()
         if overlap:
             self.red_g.zero_grad()
@@ -287,11 +312,18 @@ class Trainer:
         return {"loss/d": loss_d.detach(), "d/real": d_reals.detach().mean(), "d/fake": d_fakes.detach().mean(), "loss/g": loss_g.detach()}
 
 
-def synthetic_reals(cfg: TrainConfig, device: torch.device, local_batch: int, seed: int = 0) -> Callable[[], Tensor]:
+def synthetic_reals(cfg: TrainConfig, device: torch.device, local_batch: int, seed: int = 0, rank: int = 0, world: int = 1) -> Callable[[], Tensor]:
     """CelebA-shaped stand-in: N(0,1) images (the real pipeline normalises to about [-1, 1],
-    train_celeba.py:79-87), a small device-resident pool cycled so no host work sits in the step."""
+    train_celeba.py:79-87), a small device-resident pool cycled so no host work sits in the step.
+    With world > 1 every rank draws the SAME global batches (one seed) and keeps its `interleaved_shard` of each:
+    MinibatchStdDev then sees the global batch's groups (progressive_gan.py:27) and N ranks train on exactly the
+    data one rank would."""
     g = torch.Generator(device="cpu").manual_seed(seed)
-    pool = [torch.randn(local_batch, 3, cfg.img_size, cfg.img_size, generator=g).to(device) for _ in range(4)]
+    rows = interleaved_shard(local_batch * world, rank, world) if world > 1 else None
+    pool = []
+    for _ in range(4):
+        batch = torch.randn(local_batch * world, 3, cfg.img_size, cfg.img_size, generator=g)
+        pool.append((batch if rows is None else batch[rows]).to(device))
     if cfg.channels_last:
         pool = [p.contiguous(memory_format=torch.channels_last) for p in pool]
     state = {"i": 0}
@@ -316,7 +348,7 @@ def main(argv=None) -> None:
     local_batch = cfg.batch_size // world // cfg.grad_accum
     torch.manual_seed(1234 + rank)
     trainer = Trainer(cfg, device, world)
-    next_reals = synthetic_reals(cfg, device, local_batch, seed=rank)
+    next_reals = synthetic_reals(cfg, device, local_batch, seed=0, rank=rank, world=world)
     t0 = time.perf_counter()
     while trainer.step < cfg.n_iters:
         logs = trainer.train_step(next_reals)

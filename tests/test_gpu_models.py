@@ -477,6 +477,6 @@ def test_hip_graph_iteration_matches_eager(dev, monkeypatch):
         graphed, tr = run(True)
     finally:
         dist.destroy_process_group()
-    assert tr._graph is not None and len(tr._graph) == 3  # D pass | D update + G pass | G update
+    assert tr._graph is not None and len(tr._graph) == 4  # D pass | G forward (under D's all-reduce) | D update + G pass | G update
     for i, (a, b) in enumerate(zip(graphed, eager)):
         assert abs(a[0] - b[0]) <= 1e-2 * max(1.0, abs(b[0])) and abs(a[1] - b[1]) <= 1e-2 * max(1.0, abs(b[1])), (i, graphed, eager)

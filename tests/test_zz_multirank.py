@@ -27,3 +27,22 @@ def test_two_rank_bench_on_one_gpu():
     assert line["n_gpus"] == 2 and line["config"]["per_gpu_batch"] == 8
     assert line["config"]["hip_graph"] and line["config"]["losses_finite"]
     assert line["roofline"] is not None and line["value"] > 0
+
+
+def test_two_rank_trainer_matches_global_batch():
+    """Two ranks, one GPU: the real Trainer on interleaved shards of one global batch (global random draws, sliced)
+    must hand the optimizers the global-batch gradients -- D (hinge + R1, MinibatchStdDev included) and G -- on the
+    hook path (bucketed all-reduces) and on the cut path the HIP graphs capture (tests/dp_parity_worker.py)."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GAN_AMD_ONE_GPU="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29573", os.path.join(root, "tests", "dp_parity_worker.py")]
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=150)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    assert "DP_PARITY_OK" in out.stdout

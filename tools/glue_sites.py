@@ -55,8 +55,8 @@ for _ in range(2):
     tr.train_step(nxt)
 torch.cuda.synchronize()
 with Spy():
-    for red in tr._iteration(nxt, overlap=False):  # the op sequence the HIP graphs capture
-        tr._flat_allreduce(red)
+    for cut in tr._iteration(nxt, overlap=False):  # the op sequence the HIP graphs capture
+        tr._exchange(*cut)
     torch.cuda.synchronize()
 by_site = collections.Counter()
 for (site, name, shape), n in counts.items():

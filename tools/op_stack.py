@@ -15,8 +15,8 @@ for _ in range(2):
     tr.train_step(nxt)
 torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
-    for red in tr._iteration(nxt, overlap=False):  # the op sequence the HIP graphs capture
-        tr._flat_allreduce(red)
+    for cut in tr._iteration(nxt, overlap=False):  # the op sequence the HIP graphs capture
+        tr._exchange(*cut)
     torch.cuda.synchronize()
 agg = collections.Counter()
 tot = collections.Counter()
