@@ -57,6 +57,8 @@ def parse():
     ap.add_argument("--no_roofline", action="store_true")
     ap.add_argument("--no_graph", action="store_true", help="launch every kernel from the host instead of replaying the iteration as HIP graphs")
     ap.add_argument("--micro_only", action="store_true", help="run only the upfirdn2d microbenchmark leg and print it")
+    ap.add_argument("--no_side", action="store_true", help="skip BASELINE configs 3 and 5 (extra keys of the JSON line)")
+    ap.add_argument("--no_pmc", action="store_true", help="skip the PMC traffic passes (roofline.traffic stays null)")
     return ap.parse_args()
 
 
@@ -114,6 +116,15 @@ def roofline_leg(trainer, next_reals):
             gbs=round(d["bytes"] / sec / 1e9, 1), bound="mfma" if mfma else "hbm",
             frac=round(d["flops"] / sec / 1e12 / MFMA_BF16_PEAK_TFLOPS if mfma else d["bytes"] / sec / 1e9 / HBM_PEAK_GBS, 4),
         )
+    # the thin direct convolution is ONE kernel template compiled per (Cin, Cout, k, mode): one aggregated row too, so that
+    # the table says where the time is and not how finely a family is split
+    thin = [v for k, v in table.items() if k.startswith("conv2d_fwd_thin<")]
+    if thin:
+        ms = sum(v["ms"] for v in thin)
+        fl, by = sum(v["flops"] for v in thin), sum(v["bytes"] for v in thin)
+        fams["conv2d_fwd_thin<*> (all instantiations)"] = dict(
+            launches=sum(v["launches"] for v in thin), ms=round(ms, 3), share=round(ms / total_ms, 4), tflops=round(fl / ms / 1e9, 2),
+            gbs=round(by / ms / 1e6, 1), bound="hbm", frac=round(by / ms / 1e6 / HBM_PEAK_GBS, 4))
     dom = max(table, key=lambda k: table[k]["ms"])
     d = table[dom]
     sec = d["ms"] * 1e-3
@@ -130,7 +141,81 @@ def roofline_leg(trainer, next_reals):
         roof = dict(kernel=dom, symbol=("conv_thin_k" + dom[len("conv2d_fwd_thin"):] if dom.startswith("conv2d_fwd_thin") else HBM_FAMILIES.get(dom, dom + "_k")), bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(ach / HBM_PEAK_GBS, 4), traffic=None,
                     launches=d["launches"], avg_launch_us=round(d["ms"] * 1e3 / d["launches"], 2))
+    if thin:
+        roof["largest_family"] = dict(name="conv2d_fwd_thin<*> (all instantiations)", **{k: fams["conv2d_fwd_thin<*> (all instantiations)"][k]
+                                                                                        for k in ("launches", "ms", "share", "gbs", "bound", "frac")})
     return roof, fams
+
+
+def pmc_traffic_leg(roof):
+    """HBM-side bytes per launch of the dominant kernel from the PMC counters (MI355X_MICROARCH.md, HBM section):
+    FETCH_SIZE and WRITE_SIZE need a rocprofv3 pass each, so two child processes run that kernel on its most common
+    shape of the workload (tools/bench_op.py) under `rocprofv3 --pmc`; FETCH_SIZE is in KB and is doubled for 16-byte
+    per lane streaming reads on gfx950, WRITE_SIZE is in KB and exact.  Returns None when the profiler is unavailable."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    shapes = {  # family -> (tools/bench_op.py arguments, kernel-name fragment, algorithmic bytes of that launch)
+        "conv2d_fwd_wide128": (["fwd", "256", "128", "32", "32", "128", "3"], "conv_wide_k<128", 2 * (256 * 32 * 32 * 128) * 2 + 128 * 1152 * 2),
+        "conv2d_fwd_wide64": (["fwd", "32", "512", "8", "8", "512", "3"], "conv_wide_k<64", 2 * (32 * 8 * 8 * 512) * 2 + 512 * 4608 * 2),
+        "conv2d_wgrad": (["wgrad", "256", "128", "32", "32", "128", "3"], "conv_wgrad_tiled_k", 2 * (256 * 32 * 32 * 128) * 2 + 128 * 1152 * 4),
+        "conv2d_wgrad_thin": (["wgrad", "256", "16", "256", "256", "16", "3"], "conv_thin_wgrad_k", 2 * (256 * 256 * 256 * 16) * 2),
+    }
+    if roof is None or roof["kernel"] not in shapes or shutil.which("rocprofv3") is None:
+        return None
+    op_args, frag, algo = shapes[roof["kernel"]]
+    vals = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        tmp = tempfile.mkdtemp(prefix="gan_amd_pmc_")
+        try:
+            cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "-d", tmp, "-o", "pmc", "--output-format", "csv", "--",
+                   sys.executable, os.path.join(ROOT, "tools", "bench_op.py")] + op_args + ["4"]
+            env = dict(os.environ, TMPDIR="/tmp")
+            subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=120)
+            got = []
+            for path in glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True):
+                with open(path) as f:
+                    for row in csv.DictReader(f):
+                        if frag in row.get("Kernel_Name", "") and row.get("Counter_Name") == counter:
+                            got.append(float(row["Counter_Value"]))
+            if not got:
+                return None
+            vals[counter] = got[-1] * 1024.0  # KB -> bytes, the last (warm) launch
+        except Exception:
+            return None
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+    return dict(bytes=round(2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]), read_bytes=round(2.0 * vals["FETCH_SIZE"]), write_bytes=round(vals["WRITE_SIZE"]),
+                algorithmic_bytes=algo, shape="tools/bench_op.py " + " ".join(op_args),
+                note="per launch of " + frag + ">; FETCH_SIZE (KB) x 2 for 16-byte-per-lane reads on gfx950 + WRITE_SIZE (KB), one rocprofv3 --pmc pass each")
+
+
+def side_recipe(device, recipe, img_size, base_dim, batch, steps=10, warmup=2):
+    """BASELINE configs 3 and 5 beside the headline line: the same timing protocol on one GPU (graph replay, W warm-up,
+    K timed steps) and the event-bracketed iteration's dominant family."""
+    from gan_amd.train_celeba import synthetic_reals
+
+    ns = argparse.Namespace(global_batch=batch, micro_batch=256, recipe=recipe, img_size=img_size, base_dim=base_dim, fp32=False, no_graph=False)
+    cfg, trainer, micro = make_trainer(ns, device, 1)
+    next_reals = synthetic_reals(cfg, device, micro, seed=0)
+    for _ in range(cfg.graph_warmup + 1 + warmup):
+        trainer.train_step(next_reals)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        trainer.train_step(next_reals)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    roof, _ = roofline_leg(trainer, next_reals)
+    graphed = bool(cfg.hip_graph and trainer._graph is not None)
+    del trainer
+    torch.cuda.empty_cache()
+    return dict(img_per_s=round(batch / dt, 1), ms_per_step=round(dt * 1e3, 2), steps=steps, warmup=warmup, hip_graph=graphed, roofline=roof,
+                workload=(f"DCGAN WGAN-GP n_disc=5, {img_size}x{img_size}, batch {batch}, Adam(1e-4, (0, 0.9)), bf16" if recipe == "dcgan" else
+                          f"StyleGAN2 hinge+R1, {img_size}x{img_size}, base_dim {base_dim}, batch {batch}, Adam(2e-4, (0, 0.9)), bf16"))
 
 
 def micro_leg(device):
@@ -177,9 +262,40 @@ def micro_leg(device):
         rec["down2_fir4_gbs"] = round(2 * 1.25 * numel / t / 1e9, 1)
         out[key] = rec
         del x
+    # benchmark_upfirdn2d.py:15-29 as written: out = f(x) ** (n_backward + 1), then n_backward times
+    # (out,) = autograd.grad(out.sum(), data, create_graph=True); 10 warm-up + N timed iterations, each followed by a
+    # device synchronise; f = UpFIRDn2d.apply(data, kernel, 1, 1, 1, 1, 1, 1) (the Function whose backward re-enters
+    # the same HIP kernel: no autograd-of-autograd over torch ops at any order).  it/s, the reference's unit.
+    from gan_amd.modelling.nvidia_ops import UpFIRDn2d
+
+    def its(data, kern, n_backward, n_iter):
+        def one():
+            o = UpFIRDn2d.apply(data, kern, 1, 1, 1, 1, 1, 1) ** (n_backward + 1)
+            for _ in range(n_backward):
+                (o,) = torch.autograd.grad(o.sum(), data, create_graph=True)
+
+        for _ in range(10):
+            one()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n_iter):
+            one()
+            torch.cuda.synchronize()
+        return n_iter / (time.perf_counter() - t0)
+
+    for shp in shapes:
+        data = torch.randn(shp, device=device, dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        n_iter = 100 if data.numel() < (1 << 28) else 30
+        rec = out["x".join(map(str, shp))]
+        rec["its_per_s_n_backward"] = {str(nb): round(its(data, k3, nb, n_iter), 1) for nb in range(3)}
+        rec["timed_iters"] = n_iter
+        del data
+        torch.cuda.empty_cache()
     big = out["32x16x1024x1024"]
     return dict(shapes=out, peak_gbs=HBM_PEAK_GBS, fir3_frac_at_largest=round(big["fir3_gbs"] / HBM_PEAK_GBS, 4),
-                bias_lrelu_frac_at_largest=round(big["bias_lrelu_gbs"] / HBM_PEAK_GBS, 4))
+                bias_lrelu_frac_at_largest=round(big["bias_lrelu_gbs"] / HBM_PEAK_GBS, 4),
+                method="*_gbs: raw kernel launches, events over 100 (20) launches, algorithmic bytes (in + out) * 2; "
+                       "its_per_s_n_backward: benchmark_upfirdn2d.py:15-29 on UpFIRDn2d.apply, bf16 channels_last")
 
 
 def cpu_leg(args):
@@ -285,11 +401,21 @@ def main():
             roof, fams = r
     if world > 1:
         dist.barrier()
+    side = None
     if rank == 0 and world == 1:
         del trainer
         torch.cuda.empty_cache()
+        if not args.no_side and args.recipe == "stylegan2" and args.img_size == 256:
+            side = {"config3_stylegan2_64": side_recipe(device, "stylegan2", 64, 64, 64),
+                    "config5_dcgan_wgan_gp": side_recipe(device, "dcgan", 64, 16, 64)}
         if not args.no_micro:
             micro_res = micro_leg(device)
+        if roof is not None and not args.no_pmc:
+            torch.cuda.synchronize()
+            tr = pmc_traffic_leg(roof)
+            if tr is not None:
+                roof["traffic"] = tr["bytes"]
+                roof["traffic_detail"] = tr
         if not args.no_cpu:
             cpu = cpu_leg(args)
 
@@ -325,6 +451,7 @@ def main():
             "kernels": fams,
             "cpu_baseline": cpu,
             "upfirdn2d": micro_res,
+            "other_configs": side,
         }
         _emit(line)
     if world > 1:

@@ -1,6 +1,7 @@
 """Micro-driver for upfirdn2d (profiling aid): python tools/bench_fir.py N C H W [up down] [iters]"""
 import sys, torch
-sys.path.insert(0, '.')
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import gan_amd.functional as GF
 from gan_amd.modelling.nvidia_ops import Blur
 n, c, h, w = map(int, sys.argv[1:5])

@@ -1,6 +1,7 @@
 """Micro-driver for one library op (profiling aid): python tools/bench_op.py wgrad N Cin H W Cout k [iters]"""
 import sys, torch
-sys.path.insert(0, '.')
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import gan_amd.functional as GF
 op = sys.argv[1]
 n, cin, h, w, cout, k = map(int, sys.argv[2:8])
