@@ -1125,6 +1125,111 @@ class MbstdBwdFn(Function):
         return gx2, (ggstat.to(ctx.gstat_dtype) if ggstat is not None else None), None
 
 
+class InstNormAffineFn(Function):
+    """y = lrelu_slope( instance_norm(x) * gamma[n, c] + beta[n, c] ): AdaIN (modelling/common.py:13-16; F.instance_norm:
+    biased variance over H x W, eps 1e-5) with the LeakyReLU that follows it in the StyleGAN generator block
+    (stylegan.py:33-34).  Forward: statistics kernel + one affine pass; backward: two channel reductions + one pass
+        gx = r * gamma * (gz - mean(gz) - xhat * mean(gz * xhat)),   gz = g * lrelu'(y),
+    written as gz * a1 + x * a2 + a3 with per-(sample, channel) coefficients (kernel gan_chan_lin2).
+    First order only: the generator never sits inside a create_graph region (train_celeba.py:128-129)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, slope, eps):
+        require_gpu(x, gamma, beta)
+        lib = _lib.load()
+        xc = as_cl(x.detach())
+        n, c, h, w = xc.shape
+        g32 = _f32(gamma).reshape(n, c)
+        b32 = _f32(beta).reshape(n, c)
+        mean = torch.empty((n, c), dtype=torch.float32, device=xc.device)
+        rstd = torch.empty_like(mean)
+        check(lib.gan_chan_stats(ptr(xc), ptr(mean), ptr(rstd), n, h * w, c, float(eps), dtype_code(xc), stream_of(xc)), "gan_chan_stats")
+        a = rstd * g32
+        b = b32 - mean * a
+        y = torch.empty_like(xc)
+        check(_run("chan_affine", 0, _nbytes(xc, y),
+                   lambda: lib.gan_chan_affine(ptr(xc), ptr(a), ptr(b), ptr(y), n, h * w, c, float(slope), dtype_code(xc), stream_of(xc)), (n, c, h, w)),
+              "gan_chan_affine")
+        ctx.save_for_backward(xc, g32, mean, rstd, y if slope != 1.0 else None)
+        ctx.slope = slope
+        ctx.meta = (gamma.shape, gamma.dtype, beta.shape, beta.dtype, x.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        if torch.is_grad_enabled():
+            raise _lib.GanAmdError("AdaIN: second-order derivatives are not implemented (generator-side op)")
+        xc, g32, mean, rstd, y = ctx.saved_tensors
+        n, c, h, w = xc.shape
+        hw = float(h * w)
+        gc = as_cl(g.detach().to(xc.dtype))
+        s1 = raw_chan_dot(gc, None, 0, y, ctx.slope, True)   # sum gz
+        sx = raw_chan_dot(gc, xc, 1, y, ctx.slope, True)     # sum gz * x
+        s2 = rstd * (sx - mean * s1)                         # sum gz * xhat
+        gamma_shape, gamma_dtype, beta_shape, beta_dtype, x_dtype = ctx.meta
+        ggamma = s2.reshape(gamma_shape).to(gamma_dtype) if _need(ctx, 1) else None
+        gbeta = s1.reshape(beta_shape).to(beta_dtype) if _need(ctx, 2) else None
+        gx = None
+        if _need(ctx, 0):
+            a1 = rstd * g32
+            a2 = -(rstd * a1 * s2) / hw
+            a3 = -(a1 * s1) / hw - a2 * mean
+            gx = torch.empty_like(xc)
+            check(_run("chan_lin2", 0, _nbytes(gc, xc, gx, y),
+                       lambda: _lib.load().gan_chan_lin2(ptr(gc), ptr(y), ptr(xc), ptr(a1.contiguous()), ptr(a2.contiguous()), ptr(a3.contiguous()),
+                                                         ptr(gx), n, h * w, c, float(ctx.slope), dtype_code(xc), stream_of(xc)), (n, c, h, w)),
+                  "gan_chan_lin2")
+            gx = gx.to(x_dtype)
+        return gx, ggamma, gbeta, None, None
+
+
+def instance_norm_affine(x: Tensor, gamma: Tensor, beta: Tensor, slope: float = 1.0, eps: float = 1e-5) -> Tensor:
+    return InstNormAffineFn.apply(x, gamma, beta, slope, eps)
+
+
+class LayerNorm2dFn(Function):
+    """y = lrelu_slope( LayerNorm_over_channels(x) * w[c] + b[c] ) per pixel (modelling/common.py:19-24, eps 1e-5) with the
+    LeakyReLU that follows it in the Progressive-GAN generator (progressive_gan.py:89-90,124-125): one launch forward,
+    one backward (input gradient + both parameter gradients).  First order only (generator-side op)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, slope, eps):
+        require_gpu(x, weight, bias)
+        lib = _lib.load()
+        xc = as_cl(x.detach())
+        n, c, h, w = xc.shape
+        w32, b32 = _f32(weight).reshape(c), _f32(bias).reshape(c)
+        y = torch.empty_like(xc)
+        stats = torch.empty((n * h * w, 2), dtype=torch.float32, device=xc.device)
+        check(_run("layernorm2d", 0, _nbytes(xc, y),
+                   lambda: lib.gan_layernorm2d_fwd(ptr(xc), ptr(w32), ptr(b32), ptr(y), ptr(stats), n * h * w, c, float(eps), float(slope),
+                                                   dtype_code(xc), stream_of(xc)), (n, c, h, w)), "gan_layernorm2d_fwd")
+        ctx.save_for_backward(xc, w32, stats, y if slope != 1.0 else None)
+        ctx.slope = slope
+        ctx.meta = (weight.shape, weight.dtype, bias.shape, bias.dtype, x.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        if torch.is_grad_enabled():
+            raise _lib.GanAmdError("LayerNorm2d: second-order derivatives are not implemented (generator-side op)")
+        xc, w32, stats, y = ctx.saved_tensors
+        n, c, h, w = xc.shape
+        gc = as_cl(g.detach().to(xc.dtype))
+        gx = torch.empty_like(xc) if _need(ctx, 0) else None
+        gwb = torch.empty((2, c), dtype=torch.float32, device=xc.device)
+        check(_run("layernorm2d_bwd", 0, _nbytes(gc, xc, gx, y),
+                   lambda: _lib.load().gan_layernorm2d_bwd(ptr(gc), ptr(xc), ptr(y), ptr(w32), ptr(stats), ptr(gx), ptr(gwb), n * h * w, c,
+                                                           float(ctx.slope), dtype_code(xc), stream_of(xc)), (n, c, h, w)), "gan_layernorm2d_bwd")
+        wshape, wdtype, bshape, bdtype, x_dtype = ctx.meta
+        return ((gx.to(x_dtype) if gx is not None else None), (gwb[0].reshape(wshape).to(wdtype) if _need(ctx, 1) else None),
+                (gwb[1].reshape(bshape).to(bdtype) if _need(ctx, 2) else None), None, None)
+
+
+def layer_norm2d(x: Tensor, weight: Tensor, bias: Tensor, slope: float = 1.0, eps: float = 1e-5) -> Tensor:
+    return LayerNorm2dFn.apply(x, weight, bias, slope, eps)
+
+
 class MbstdConcatFn(Function):
     """(x (N, C, H, W), stat (N/G,)) -> (N, C+1, H, W): the statistic of each sample's group column appended as a
     constant plane (progressive_gan.py:31-36), one launch.  Linear in both arguments; its adjoint is

@@ -65,9 +65,39 @@ class Upsample(nn.Upsample):
         return GF.nearest_up2(to_act(x))
 
 
+class AdaIN(nn.Module):
+    """modelling/common.py:7-16: F.instance_norm(x) * (style_w(w) + 1) + style_b(w), as statistics + one affine pass."""
+
+    def __init__(self, dim: int, z_dim: int) -> None:
+        super().__init__()
+        self.style_w = nn.Linear(z_dim, dim)
+        self.style_b = nn.Linear(z_dim, dim)
+
+    def fused(self, x: Tensor, w: Tensor, slope: float) -> Tensor:
+        """AdaIN followed by LeakyReLU(slope) (stylegan.py:33-34) in the same pass; slope = 1: AdaIN alone."""
+        with torch.autocast("cuda", enabled=False):  # (N, z) x (z, C): fp32 costs nothing here
+            gamma = self.style_w(w.float()) + 1
+            beta = self.style_b(w.float())
+        return GF.instance_norm_affine(to_act(x), gamma, beta, slope)
+
+    def forward(self, x: Tensor, w: Tensor) -> Tensor:
+        return self.fused(x, w, 1.0)
+
+
+class LayerNorm2d(nn.LayerNorm):
+    """modelling/common.py:19-24: nn.LayerNorm over the channel axis of an (N, C, H, W) tensor; channels-last makes that
+    a row normalisation of each pixel."""
+
+    def fused(self, x: Tensor, slope: float) -> Tensor:
+        return GF.layer_norm2d(to_act(x), self.weight, self.bias, slope, self.eps)
+
+    def forward(self, x: Tensor) -> Tensor:
+        return self.fused(x, 1.0)
+
+
 def get_norm(norm: str, dim: int):
-    """modelling/common.py:27-33 -- only the entries the hot path uses ("none" for the StyleGAN2/DCGAN D)."""
-    return dict(none=nn.Identity, batch=partial(nn.BatchNorm2d, track_running_stats=False))[norm](dim)
+    """modelling/common.py:27-33 ("instance" is only used by models outside this build's scope)."""
+    return dict(none=nn.Identity, batch=partial(nn.BatchNorm2d, track_running_stats=False), layer=LayerNorm2d)[norm](dim)
 
 
 def get_act(act: str):

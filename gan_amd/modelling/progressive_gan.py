@@ -104,6 +104,72 @@ class ProgressiveGanDiscriminator(nn.Sequential):
         return flat(x).float()
 
 
+class ProgressiveGanGeneratorBlock(nn.Module):
+    """progressive_gan.py:85-100: shortcut(x) + layers(x) * scale with layers = LayerNorm2d -> LeakyReLU -> Upsample ->
+    Conv3x3 -> LeakyReLU -> Conv3x3 and shortcut = Conv1x1 -> Upsample.  Launches: LayerNorm2d + LeakyReLU; Upsample +
+    Conv (nearest 2x in the gather: leaky-ReLU and nearest upsampling commute); LeakyReLU + Conv; Conv1x1; scale; skip."""
+
+    def __init__(self, in_dim: int, out_dim: int) -> None:
+        super().__init__()
+        from .common import LayerNorm2d, Upsample
+
+        self.layers = nn.Sequential(
+            LayerNorm2d(in_dim),
+            LeakyReLU(0.2),
+            Upsample(scale_factor=2.0),
+            Conv2d(in_dim, out_dim, 3, 1, 1),
+            LeakyReLU(0.2),
+            Conv2d(out_dim, out_dim, 3, 1, 1),
+        )
+        self.shortcut = nn.Sequential(Conv2d(in_dim, out_dim, 1), Upsample(scale_factor=2.0))
+        self.scale = nn.Parameter(torch.full((out_dim, 1, 1), 1e-4))
+
+    def forward(self, x: Tensor) -> Tensor:
+        from .stylegan2 import ModConvFn
+
+        x = to_act(x)
+        norm, act0, _, conv1, act1, conv2 = self.layers
+        h = norm.fused(x, act0.negative_slope)
+        h = ModConvFn.apply(h, conv1.weight, None, None, conv1.bias, None, None, 1.0, True)
+        h = GF.conv_bias_act(h, conv2.weight, conv2.bias, conv2.padding[0], 1.0, act1.negative_slope)
+        s = self.shortcut[0](x)
+        return GF.up2_add(s, GF.affine_act(h, a=self.scale.reshape(-1)))
+
+
+class ProgressiveGanGenerator(nn.Sequential):
+    """progressive_gan.py:103-133 (same child layout and state_dict keys)."""
+
+    def __init__(self, img_size: int, img_channels: int = 3, z_dim: int = 128, base_dim: int = 16) -> None:
+        super().__init__()
+        from .common import LayerNorm2d, _ConvTranspose2d
+
+        out_ch = min(base_dim * img_size // 4, 512)
+        self.append(nn.Sequential(nn.LayerNorm(z_dim), nn.Unflatten(-1, (-1, 1, 1)), _ConvTranspose2d(z_dim, out_ch, 4)))
+        in_ch = out_ch
+
+        depth = int(math.log2(img_size // 4))
+        for i in range(depth):
+            out_ch = min(base_dim * img_size // 4 // 2 ** (i + 1), 512)
+            self.append(ProgressiveGanGeneratorBlock(in_ch, out_ch))
+            in_ch = out_ch
+
+        self.append(nn.Sequential(LayerNorm2d(in_ch), LeakyReLU(0.2), Conv2d(in_ch, img_channels, 1)))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        self.apply(init_weights)
+
+    def forward(self, z: Tensor) -> Tensor:
+        first, *blocks, last = list(self)
+        with torch.autocast("cuda", enabled=False):
+            zn = first[0](z.float())
+        x = first[2](first[1](zn).to(GF.act_dtype(z)))
+        for blk in blocks:
+            x = blk(x)
+        norm, act, conv = last
+        return conv(norm.fused(x, act.negative_slope))
+
+
 def init_weights(module: nn.Module):
     """kaiming-normal weights, zero biases on every conv / linear (progressive_gan.py:136-140)."""
     if isinstance(module, (nn.modules.conv._ConvNd, nn.Linear)):

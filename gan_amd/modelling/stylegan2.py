@@ -52,6 +52,9 @@ def batched_conv2d(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, str
 
 class ModConvFn(Function):
     """y = lrelu_slope( dinv * conv(U(x) * s, W) + b + noise * ns ),  U = nearest x2 if up2.
+    s, dinv, b, noise / ns may each be None: with s = dinv = None this is the plain fused
+    [Upsample ->] Conv2d -> Noise -> LeakyReLU of the StyleGAN-v1 / Progressive-GAN generator blocks
+    (stylegan.py:35-38, progressive_gan.py:91-92).
 
     Forward: one fused kernel.  Backward without create_graph: hand-written kernels (leaky-ReLU
     mask + demod scale in one pass, channel reductions for b / ns / dinv, dgrad, wgrad with the
@@ -108,7 +111,7 @@ class ModConvFn(Function):
             elif need[2]:
                 gs = GF.raw_chan_dot(gxs, x, 1, None, 1.0, True).reshape(s.shape).to(s.dtype)
             else:
-                gx = GF.raw_mask_scale(gxs, None, s, 1.0)
+                gx = GF.raw_mask_scale(gxs, None, s, 1.0) if s is not None else gxs
         if need[1]:
             gw = GF.raw_conv2d_wgrad(x, gz, kh, kh, pad, pad, up2=up2, in_scale=s).to(weight.dtype)
         return gx, gw, gs, gdinv, gb, None, gns, None, None
@@ -125,7 +128,7 @@ class ModConvFn(Function):
         kh, kw = weight.shape[2], weight.shape[3]
         gp = GF.MaskMulFn.apply(gy, y, slope) if slope != 1.0 else gy  # gradient at the pre-activation
         xu = GF.nearest_up2(x) if up2 else x
-        xs = GF.ChanScaleFn.apply(xu, s)
+        xs = GF.ChanScaleFn.apply(xu, s) if s is not None else xu
         gx = gw = gs = gdinv = gb = gns = None
         if bias is not None and need[4]:
             gb = GF.ChanSumFn.apply(gp, False).reshape(bias.shape).to(bias.dtype)
@@ -142,7 +145,7 @@ class ModConvFn(Function):
             if need[2]:
                 gs = GF.ChanDotFn.apply(gxs, xu, True).reshape(s.shape).to(s.dtype)
             if need[0]:
-                gx = GF.ChanScaleFn.apply(gxs, s)
+                gx = GF.ChanScaleFn.apply(gxs, s) if s is not None else gxs
                 if up2:  # adjoint of nearest x2: sum of each 2x2 block
                     gx = GF.UpFirDnFn.apply(gx, GF._ones_taps(gx, 1.0), 1, 2, 0, 0, 0, 0)
         if need[1]:

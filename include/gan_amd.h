@@ -223,6 +223,28 @@ int gan_mbstd_bwd2(const void* x, const float* gstat, const void* u, void* gx2, 
 int gan_mbstd_concat(const void* x, const float* stat, void* out, int N, int G, int64_t HW, int C, int dtype, gan_stream_t stream);
 int gan_mbstd_concat_adj(const void* g, void* gx, float* gstat, int N, int G, int64_t HW, int C, int dtype, gan_stream_t stream);
 
+/* ---- AdaIN / LayerNorm2d (the StyleGAN-v1 and Progressive-GAN generators) ------------------------------------
+ * replaces AdaIN.forward              modelling/common.py:13-16   F.instance_norm(x) * (style_w(w) + 1) + style_b(w)
+ *          LayerNorm2d.forward        modelling/common.py:20-24   nn.LayerNorm over the channels of each pixel
+ *          and the LeakyReLU(0.2) that follows them (stylegan.py:33-34, progressive_gan.py:89-90,124-125).
+ * gan_chan_stats : mean[n][c], rstd[n][c] = 1 / sqrt(var + eps) of x [N][HW][C] over the pixels (biased variance).
+ * gan_chan_affine: y = lrelu_slope(x * a[n][c] + b[n][c])  (AdaIN with a = rstd * gamma, b = beta - mean * a).
+ * gan_chan_lin2  : out = g * m(ymask) * a1[n][c] + x * a2[n][c] + a3[n][c]  (its input gradient in one pass; ymask may be
+ *                  NULL).  a, b, a1..a3, mean, rstd: fp32 [N][C].
+ * gan_layernorm2d_fwd: y[p][c] = lrelu_slope((x[p][c] - mean_p) * rstd_p * w[c] + b[c]); stats: fp32 [NP][2] = (mean_p,
+ *                  rstd_p), kept for the backward pass; NP = N*H*W pixels.
+ * gan_layernorm2d_bwd: gx (NULL: skipped) and gwb fp32 [2][C] = (gradient of w, gradient of b), zeroed here; g is multiplied
+ *                  by the leaky-ReLU mask of ymask (the forward's output; NULL = no activation). */
+int gan_chan_stats(const void* x, float* mean, float* rstd, int N, int64_t HW, int C, float eps, int dtype, gan_stream_t stream);
+int gan_chan_affine(const void* x, const float* a, const float* b, void* y, int N, int64_t HW, int C, float slope, int dtype,
+                    gan_stream_t stream);
+int gan_chan_lin2(const void* g, const void* ymask, const void* x, const float* a1, const float* a2, const float* a3, void* out, int N,
+                  int64_t HW, int C, float slope, int dtype, gan_stream_t stream);
+int gan_layernorm2d_fwd(const void* x, const float* w, const float* b, void* y, float* stats, int64_t NP, int C, float eps, float slope,
+                        int dtype, gan_stream_t stream);
+int gan_layernorm2d_bwd(const void* g, const void* x, const void* ymask, const float* w, const float* stats, void* gx, float* gwb,
+                        int64_t NP, int C, float slope, int dtype, gan_stream_t stream);
+
 /* ---- EMA ---------------------------------------------------------------------------------
  * replaces the per-parameter lerp_ loop of EMA.step   utils.py:95-96
  * ema[i] += (p[i] - ema[i]) * weight over one flat fp32 arena. */

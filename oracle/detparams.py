@@ -47,6 +47,8 @@ def det_state(shapes: Mapping[str, tuple], seed: int, *, bias_amp: float = 0.1, 
         elif name.endswith("weight") and len(shape) >= 2:
             fan_in = int(np.prod(shape[1:]))
             t = u * math.sqrt(12.0) * math.sqrt(2.0 / fan_in)
+        elif name.endswith("weight") and len(shape) == 1:  # LayerNorm / LayerNorm2d gains
+            t = 1 + 0.2 * u
         elif name.endswith("scale"):
             t = u * 2 * scale_amp
         else:

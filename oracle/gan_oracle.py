@@ -248,6 +248,63 @@ def discriminator(sd: Mapping[str, Tensor], imgs: Tensor) -> Tensor:
 
 
 # --------------------------------------------------------------------------------------
+# modelling/stylegan.py (StyleGAN v1 generator) + modelling/progressive_gan.py:85-133 (Progressive GAN generator)
+# + modelling/common.py:7-24 (AdaIN, LayerNorm2d)
+# --------------------------------------------------------------------------------------
+def adain(x: Tensor, w: Tensor, sw_w: Tensor, sw_b: Tensor, sb_w: Tensor, sb_b: Tensor) -> Tensor:
+    """AdaIN.forward (common.py:13-16): instance norm (biased variance over H x W, eps 1e-5) * (style_w(w) + 1) + style_b(w)."""
+    weight = (F.linear(w, sw_w, sw_b) + 1)[:, :, None, None]
+    bias = F.linear(w, sb_w, sb_b)[:, :, None, None]
+    mean = x.mean(dim=(2, 3), keepdim=True)
+    var = (x - mean).square().mean(dim=(2, 3), keepdim=True)
+    return (x - mean) / (var + 1e-5).sqrt() * weight + bias
+
+
+def layer_norm2d(x: Tensor, weight: Tensor, bias: Tensor) -> Tensor:
+    """LayerNorm2d.forward (common.py:20-24): LayerNorm over the channels of each pixel, eps 1e-5."""
+    mean = x.mean(dim=1, keepdim=True)
+    var = (x - mean).square().mean(dim=1, keepdim=True)
+    return (x - mean) / (var + 1e-5).sqrt() * weight.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1)
+
+
+def stylegan_generator(sd: Mapping[str, Tensor], z: Tensor, noises: Optional[Sequence[Tensor]] = None) -> Tensor:
+    """StyleGanGenerator.forward (stylegan.py:76-85); block = [AdaIN, LeakyReLU, Upsample, Conv, Noise, LeakyReLU, Conv, Noise]
+    (stylegan.py:30-47); w = mapping_network(z) * 0.01."""
+    feed = _NoiseFeed(noises)
+    w = mapping_network(sd, z) * 0.01
+    n_blocks = 1 + max(int(k.split(".")[1]) for k in sd if k.startswith("blocks."))
+    x = sd["learned_input"].expand(z.shape[0], -1, -1, -1)
+    out = None
+    for b in range(n_blocks):
+        p = f"blocks.{b}."
+        x = adain(x, w, sd[p + "0.style_w.weight"], sd[p + "0.style_w.bias"], sd[p + "0.style_b.weight"], sd[p + "0.style_b.bias"])
+        x = nearest_up2(F.leaky_relu(x, SLOPE))
+        x = F.conv2d(x, sd[p + "3.weight"], sd[p + "3.bias"], padding=1)
+        x = F.leaky_relu(add_noise(x, sd[p + "4.scale"], feed.next()), SLOPE)
+        x = F.conv2d(x, sd[p + "6.weight"], sd[p + "6.bias"], padding=1)
+        x = add_noise(x, sd[p + "7.scale"], feed.next())
+        rgb = F.conv2d(x, sd[f"out_convs.{b}.weight"], sd[f"out_convs.{b}.bias"])
+        out = rgb if out is None else nearest_up2(out) + rgb
+    return out
+
+
+def progan_generator(sd: Mapping[str, Tensor], z: Tensor) -> Tensor:
+    """ProgressiveGanGenerator (progressive_gan.py:103-133) with its blocks (progressive_gan.py:85-100)."""
+    last = max(int(k.split(".")[0]) for k in sd)
+    h = F.layer_norm(z, z.shape[-1:], sd["0.0.weight"], sd["0.0.bias"])
+    x = F.conv_transpose2d(h[:, :, None, None], sd["0.2.weight"], sd["0.2.bias"])
+    for b in range(1, last):
+        p = f"{b}."
+        h = F.leaky_relu(layer_norm2d(x, sd[p + "layers.0.weight"], sd[p + "layers.0.bias"]), SLOPE)
+        h = F.conv2d(nearest_up2(h), sd[p + "layers.3.weight"], sd[p + "layers.3.bias"], padding=1)
+        h = F.conv2d(F.leaky_relu(h, SLOPE), sd[p + "layers.5.weight"], sd[p + "layers.5.bias"], padding=1)
+        s = nearest_up2(F.conv2d(x, sd[p + "shortcut.0.weight"], sd[p + "shortcut.0.bias"]))
+        x = s + h * sd[p + "scale"]
+    x = F.leaky_relu(layer_norm2d(x, sd[f"{last}.0.weight"], sd[f"{last}.0.bias"]), SLOPE)
+    return F.conv2d(x, sd[f"{last}.2.weight"], sd[f"{last}.2.bias"])
+
+
+# --------------------------------------------------------------------------------------
 # modelling/dcgan.py + modelling/common.py (BASELINE config 5)
 # --------------------------------------------------------------------------------------
 def dcgan_discriminator(sd: Mapping[str, Tensor], imgs: Tensor) -> Tensor:

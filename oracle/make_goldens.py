@@ -411,6 +411,30 @@ def gold_trajectory():
     )
 
 
+def gold_generators_v1():
+    """StyleGanGenerator and ProgressiveGanGenerator (stylegan.py:50-85, progressive_gan.py:103-133) at 16x16, base_dim 16:
+    deterministic parameters (oracle.detparams, only the shape table is stored), recorded noise, image, loss and every
+    parameter gradient (fingerprints for the big tensors)."""
+    out = {}
+    for name, seed in (("stylegan", 31), ("progressive_gan", 32)):
+        gen = build_generator(name, img_size=16, base_dim=16)
+        for m in gen.modules():
+            if isinstance(m, nn.LeakyReLU):
+                m.inplace = False
+        shapes = {k: tuple(v.shape) for k, v in gen.state_dict().items()}
+        gen.load_state_dict(det_state(shapes, seed=seed, bias_amp=0.1, scale_amp=0.1))
+        z = det_uniform((4, 128), 940 + seed) * 3.0
+        with RandTape() as tape:
+            img = gen(z)
+        wgt = det_uniform(tuple(img.shape), 950 + seed)
+        loss = (img * wgt).sum() + img.square().mean()
+        loss.backward()
+        grads = {k: (p.grad.detach().clone() if p.numel() <= 4096 else projections(p.grad)) for k, p in gen.named_parameters()}
+        out[name] = {"seed": seed, "shapes": {k: list(v) for k, v in shapes.items()}, "z": z, "noise": tape.tape, "img": img.detach().clone(),
+                     "loss": float(loss), "grads": grads}
+    save("generators_v1", out)
+
+
 def gold_resample_convs():
     """up_conv_blur / blur_conv_down (nvidia_ops.py:81-123), all three branches of each (blur_size None, kernel_size 1,
     kernel_size 3), blur sizes 3 and 4: forward, first-order gradients of every leaf, second order through x."""
@@ -451,3 +475,4 @@ if __name__ == "__main__":
     gold_dcgan()
     gold_trajectory()
     gold_resample_convs()
+    gold_generators_v1()

@@ -480,3 +480,70 @@ def test_hip_graph_iteration_matches_eager(dev, monkeypatch):
     assert tr._graph is not None and len(tr._graph) == 4  # D pass | G forward (under D's all-reduce) | D update + G pass | G update
     for i, (a, b) in enumerate(zip(graphed, eager)):
         assert abs(a[0] - b[0]) <= 1e-2 * max(1.0, abs(b[0])) and abs(a[1] - b[1]) <= 1e-2 * max(1.0, abs(b[1])), (i, graphed, eager)
+
+
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["stylegan", "progressive_gan"])
+def test_generators_v1_golden(dev, golden, name):
+    """build_generator("stylegan" | "progressive_gan") -- AdaIN / LayerNorm2d kernels, the unmodulated fused
+    [Upsample ->] Conv -> Noise -> LeakyReLU launch, the RGB / block skips -- against the reference's image, loss and
+    parameter gradients (fp32), every gradient in full against the fp64 oracle, and under bf16 autocast."""
+    from gan_amd.modelling import build_generator
+    from oracle import gan_oracle as O
+    from oracle.detparams import det_state, det_uniform, projections
+    from oracle.tape import RandTape
+
+    g = golden("generators_v1")[name]
+    shapes = {k: tuple(v) for k, v in g["shapes"].items()}
+    state = det_state(shapes, seed=g["seed"], bias_amp=0.1, scale_amp=0.1)
+    gen = build_generator(name, img_size=16, base_dim=16)
+    assert {k: tuple(v.shape) for k, v in gen.state_dict().items()} == shapes
+    gen = _load(gen, state, dev)
+    wgt = det_uniform(tuple(g["img"].shape), 950 + g["seed"])
+    with RandTape(list(g["noise"])):
+        img = gen(g["z"].to(dev))
+    assert rel_err(img, g["img"]) < TOL, rel_err(img, g["img"])
+    loss = (img * wgt.to(dev)).sum() + img.square().mean()
+    assert math.isclose(float(loss), g["loss"], rel_tol=1e-5)
+    loss.backward()
+    named = dict(gen.named_parameters())
+    for k, ref in g["grads"].items():
+        got = named[k].grad
+        if named[k].numel() > 4096:
+            assert float((projections(got) - ref).abs().max()) < 2e-4 * float(ref[1]), (k, projections(got), ref)
+        else:
+            assert rel_err(got, ref) < TOL2, (k, rel_err(got, ref))
+    sd = {k: v.double().requires_grad_(True) for k, v in state.items()}
+    noise64 = [t.double() for t in g["noise"]]
+    img_o = O.stylegan_generator(sd, g["z"].double(), noise64) if name == "stylegan" else O.progan_generator(sd, g["z"].double())
+    ((img_o * wgt.double()).sum() + img_o.square().mean()).backward()
+    for k, v in sd.items():
+        assert rel_err(named[k].grad, v.grad) < TOL2, (k, rel_err(named[k].grad, v.grad))
+    # bf16 autocast: image within 1e-2, the gradient as one vector within 3e-2 (the oracle re-run on the noise draws as
+    # the bf16 path sees them: the Noise layer draws in the activation dtype, stylegan.py:26)
+    gen.zero_grad()
+    with RandTape(list(g["noise"])), torch.autocast("cuda", dtype=torch.bfloat16):
+        img_b = gen(g["z"].to(dev))
+    sd = {k: v.double().requires_grad_(True) for k, v in state.items()}
+    noise_b = [t.bfloat16().double() for t in g["noise"]]
+    img_o = O.stylegan_generator(sd, g["z"].double(), noise_b) if name == "stylegan" else O.progan_generator(sd, g["z"].double())
+    ((img_o * wgt.double()).sum() + img_o.square().mean()).backward()
+    # yardstick: the same oracle under torch.autocast(cpu, bf16) -- the reference arithmetic's own bf16 error (instance /
+    # layer normalisation subtract a mean: the rounding of their bf16 inputs is amplified by |mean| / std)
+    sc = {k: v.clone().requires_grad_(True) for k, v in state.items()}
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        img_c = (O.stylegan_generator(sc, g["z"], [t.bfloat16().float() for t in g["noise"]]) if name == "stylegan" else O.progan_generator(sc, g["z"])).float()
+    ((img_c * wgt).sum() + img_c.square().mean()).backward()
+
+    def total(grads):
+        num = sum(float((grads[k].double().cpu() - v.grad).square().sum()) for k, v in sd.items())
+        return (num / sum(float(v.grad.square().sum()) for v in sd.values())) ** 0.5
+
+    e_img, e_img_cpu = rel_err(img_b, img_o), rel_err(img_c, img_o)
+    # 3x for the image: under autocast the reference's Noise output is fp32 (bf16 conv output + fp32 noise * scale) and
+    # feeds AdaIN unrounded, here every activation is stored in bf16 -- one more rounding in front of a normalisation
+    assert img_b.dtype == torch.bfloat16 and e_img < max(TOLBF, 3.0 * e_img_cpu), (e_img, e_img_cpu)
+    ((img_b.float() * wgt.to(dev)).sum() + img_b.float().square().mean()).backward()
+    e_g, e_g_cpu = total({k: p.grad for k, p in named.items()}), total({k: v.grad for k, v in sc.items()})
+    print(f"{name} bf16: image {e_img:.2e} (CPU autocast {e_img_cpu:.2e}), all grads {e_g:.2e} (CPU autocast {e_g_cpu:.2e})")
+    assert e_g < max(3e-2, 2.0 * e_g_cpu), (e_g, e_g_cpu)

@@ -286,3 +286,23 @@ def test_resample_convs(golden):
                 assert t is None or float(t.abs().max()) == 0.0, (tag, n)
             else:
                 assert rel_err(t, ref) < 1e-4, (tag, n)
+
+
+@pytest.mark.parametrize("name", ["stylegan", "progressive_gan"])
+def test_generators_v1(golden, name):
+    """StyleGanGenerator / ProgressiveGanGenerator (stylegan.py:50-85, progressive_gan.py:103-133; AdaIN and LayerNorm2d,
+    common.py:7-24) against the reference's image, loss and parameter gradients."""
+    g = golden("generators_v1")[name]
+    shapes = {k: tuple(v) for k, v in g["shapes"].items()}
+    sd = leaves_of(det_state(shapes, seed=g["seed"], bias_amp=0.1, scale_amp=0.1))
+    img = O.stylegan_generator(sd, g["z"], list(g["noise"])) if name == "stylegan" else O.progan_generator(sd, g["z"])
+    assert rel_err(img, g["img"]) < TOL
+    loss = (img * det_uniform(tuple(img.shape), 950 + g["seed"])).sum() + img.square().mean()
+    assert math.isclose(float(loss), g["loss"], rel_tol=1e-5)
+    loss.backward()
+    for k, ref in g["grads"].items():
+        got = sd[k].grad
+        if sd[k].numel() > 4096:
+            assert float((projections(got) - ref).abs().max()) < 2e-4 * float(ref[1]), k
+        else:
+            assert rel_err(got, ref) < TOL2, (k, rel_err(got, ref))
