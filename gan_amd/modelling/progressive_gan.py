@@ -41,22 +41,38 @@ class MinibatchStdDev(nn.Module):
 
 
 class ProgressiveGanDiscriminatorBlock(nn.Module):
-    def __init__(self, in_dim: int, out_dim: int) -> None:
+    """blur_size (default None = the reference's block): both AvgPool2d(2) become `Blur(blur_size, down=2)` FIR
+    down-samplers, the pairing of blur_conv_down (nvidia_ops.py:104-123) -- SURVEY.md 8 f1.  AvgPool2d(2) IS
+    Blur(2, down=2) (taps [[1,1],[1,1]]/4, pads (0,1)), so blur_size=2 reproduces the reference block exactly."""
+
+    def __init__(self, in_dim: int, out_dim: int, blur_size=None) -> None:
         super().__init__()
+        if blur_size is None:
+            down = lambda: AvgPool2d(2)  # noqa: E731
+        else:
+            from .nvidia_ops import Blur
+
+            down = lambda: Blur(blur_size, down=2)  # noqa: E731
         self.layers = nn.Sequential(
             LeakyReLU(0.2),
             Conv2d(in_dim, in_dim, 3, 1, 1),
             LeakyReLU(0.2),
             Conv2d(in_dim, out_dim, 3, 1, 1),
-            AvgPool2d(2),
+            down(),
         )
-        self.shortcut = nn.Sequential(AvgPool2d(2), Conv2d(in_dim, out_dim, 1))
+        self.shortcut = nn.Sequential(down(), Conv2d(in_dim, out_dim, 1))
         self.scale = nn.Parameter(torch.full((out_dim, 1, 1), 1e-4))
 
     def forward(self, x: Tensor) -> Tensor:
         x = to_act(x)
-        act0, conv1, act1, conv2, _ = self.layers
+        act0, conv1, act1, conv2, down = self.layers
         conv_s = self.shortcut[1]
+        if not isinstance(down, AvgPool2d):
+            # FIR down-sampling: activation + convolution + bias fused per launch, the two FIR passes, the residual pass
+            h = GF.conv_bias_act(x, conv1.weight, conv1.bias, conv1.padding[0], 1.0, act0.negative_slope)
+            h = down(GF.conv_bias_act(h, conv2.weight, conv2.bias, conv2.padding[0], 1.0, act1.negative_slope))
+            s = conv_s(self.shortcut[0](x))
+            return GF.affine_act(h, a=self.scale.reshape(-1), r=s)
         # act -> conv1 (+bias) and the shortcut (pool -> conv_s; for thin layers conv_s -> pool, the same linear
         # map, in one launch) share x: one autograd node, so their input gradients come out of one kernel
         h, s = GF.DBlockInputFn.apply(x, conv1.weight, conv1.bias, conv_s.weight, act0.negative_slope, conv_s.out_channels <= 64,
@@ -67,7 +83,7 @@ class ProgressiveGanDiscriminatorBlock(nn.Module):
 
 
 class ProgressiveGanDiscriminator(nn.Sequential):
-    def __init__(self, img_size: int, img_channels: int = 3, base_dim: int = 16) -> None:
+    def __init__(self, img_size: int, img_channels: int = 3, base_dim: int = 16, blur_size=None) -> None:
         super().__init__()
         depth = int(math.log2(img_size // 4))
         self.append(Conv2d(img_channels, base_dim, 1))
@@ -75,7 +91,7 @@ class ProgressiveGanDiscriminator(nn.Sequential):
 
         for _ in range(depth):
             out_ch = min(in_ch * 2, 512)
-            self.append(ProgressiveGanDiscriminatorBlock(in_ch, out_ch))
+            self.append(ProgressiveGanDiscriminatorBlock(in_ch, out_ch, blur_size))
             in_ch = out_ch
 
         self.append(

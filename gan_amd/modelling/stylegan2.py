@@ -187,13 +187,20 @@ class ModulatedConv2d(nn.Conv2d):
 
 
 class StyleGan2GeneratorBlock(nn.Module):
-    def __init__(self, in_dim: int, out_dim: int, z_dim: int, img_channels: int, first_block: bool = False) -> None:
+    """blur_size (default None = the reference's block): a `Blur(blur_size)` FIR low-pass in the slot the reference marks
+    `# TODO: blur` (stylegan2.py:47), between the upsampling modulated convolution and its Noise -- SURVEY.md 8 f1."""
+
+    def __init__(self, in_dim: int, out_dim: int, z_dim: int, img_channels: int, first_block: bool = False,
+                 blur_size: Optional[int] = None) -> None:
         super().__init__()
         self.layers = nn.ModuleList()
         if not first_block:
-            self.layers.extend(
-                [Upsample(scale_factor=2.0), ModulatedConv2d(in_dim, out_dim, 3, z_dim), Noise(out_dim), LeakyReLU(0.2)]
-            )
+            self.layers.extend([Upsample(scale_factor=2.0), ModulatedConv2d(in_dim, out_dim, 3, z_dim)])
+            if blur_size is not None:
+                from .nvidia_ops import Blur
+
+                self.layers.append(Blur(blur_size))
+            self.layers.extend([Noise(out_dim), LeakyReLU(0.2)])
         self.layers.extend([ModulatedConv2d(out_dim, out_dim, 3, z_dim), Noise(out_dim), LeakyReLU(0.2)])
         self.to_rgb = ModulatedConv2d(out_dim, img_channels, 1, z_dim, demodulation=False)
 
@@ -222,6 +229,20 @@ class StyleGan2GeneratorBlock(nn.Module):
                 draw = torch.randn(n, 1, ho, wo, device=x.device, dtype=x.dtype)
                 x = conv.fused(x, w_embs, draw, noise_mod.scale, act.negative_slope, up2)
                 i += 3
+            elif (
+                isinstance(conv, ModulatedConv2d)
+                and i + 3 < len(layers)
+                and type(layers[i + 1]).__name__ == "Blur"
+                and isinstance(layers[i + 2], Noise)
+                and isinstance(layers[i + 3], LeakyReLU)
+            ):
+                # blur-enabled block: [Upsample +] ModConv + bias in one launch, the FIR pass, then Noise + LeakyReLU in one
+                blur, noise_mod, act = layers[i + 1], layers[i + 2], layers[i + 3]
+                x = blur(conv.fused(x, w_embs, None, None, 1.0, up2))
+                n, _, ho, wo = x.shape
+                draw = torch.randn(n, 1, ho, wo, device=x.device, dtype=x.dtype)
+                x = GF.affine_act(x, noise=draw, ns=noise_mod.scale, slope=act.negative_slope)
+                i += 4
             else:  # unfused fallback for a re-arranged ModuleList: same ops, one launch each
                 if up2:
                     x = GF.nearest_up2(x)
@@ -231,7 +252,7 @@ class StyleGan2GeneratorBlock(nn.Module):
 
 
 class StyleGan2Generator(nn.Module):
-    def __init__(self, img_size: int, img_channels: int = 3, z_dim: int = 128, base_dim: int = 16) -> None:
+    def __init__(self, img_size: int, img_channels: int = 3, z_dim: int = 128, base_dim: int = 16, blur_size: Optional[int] = None) -> None:
         super().__init__()
         self.mapping_network = nn.Sequential(nn.LayerNorm(z_dim))
         for _ in range(8):
@@ -247,7 +268,7 @@ class StyleGan2Generator(nn.Module):
         depth = int(math.log2(img_size // 4))
         for i in range(depth):
             out_ch = min(base_dim * img_size // 4 // 2 ** (i + 1), 512)
-            self.blocks.append(StyleGan2GeneratorBlock(in_ch, out_ch, z_dim, img_channels))
+            self.blocks.append(StyleGan2GeneratorBlock(in_ch, out_ch, z_dim, img_channels, blur_size=blur_size))
             in_ch = out_ch
 
         self.reset_parameters()

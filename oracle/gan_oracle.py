@@ -60,7 +60,7 @@ def blur(imgs: Tensor, size: int = 3, up: int = 1, down: int = 1) -> Tensor:
     """`Blur(size, up, down)(imgs)` (nvidia_ops.py:58-69)."""
     p1 = (size - 1) // 2
     p2 = size - 1 - p1
-    return upfirdn2d(imgs, blur_kernel(size).to(imgs.device), up, down, p1, p2, p1, p2)
+    return upfirdn2d(imgs, blur_kernel(size).to(imgs.device, imgs.dtype if imgs.dtype == torch.float64 else torch.float32), up, down, p1, p2, p1, p2)
 
 
 def nearest_up2(x: Tensor) -> Tensor:
@@ -177,25 +177,30 @@ def mapping_network(sd: Mapping[str, Tensor], z: Tensor) -> Tensor:
 
 
 def generator_block(
-    sd: Mapping[str, Tensor], prefix: str, x: Tensor, w: Tensor, first: bool, feed: _NoiseFeed
+    sd: Mapping[str, Tensor], prefix: str, x: Tensor, w: Tensor, first: bool, feed: _NoiseFeed, blur_size: Optional[int] = None
 ):
     """StyleGan2GeneratorBlock.forward with the INTENDED to_rgb(x, w) (stylegan2.py:39-64).
     ModuleList indices: first block [modconv, noise, lrelu]; later blocks
     [upsample, modconv, noise, lrelu, modconv, noise, lrelu]."""
     if first:
         convs = [(0, 1)]
-    else:
+    elif blur_size is None:
         convs = [(1, 2), (4, 5)]
         x = nearest_up2(x)
-    for ci, ni in convs:
+    else:  # blur-enabled variant (SURVEY 8 f1; no reference model: the `# TODO: blur` slot of stylegan2.py:47 filled with Blur)
+        convs = [(1, 3), (5, 6)]
+        x = nearest_up2(x)
+    for j, (ci, ni) in enumerate(convs):
         x = _modconv_from(sd, f"{prefix}layers.{ci}.", x, w, True)
+        if blur_size is not None and not first and j == 0:
+            x = blur(x, blur_size)
         x = add_noise(x, sd[f"{prefix}layers.{ni}.scale"], feed.next())
         x = bias_leaky_relu(x, None)
     rgb = _modconv_from(sd, f"{prefix}to_rgb.", x, w, False)
     return x, rgb
 
 
-def generator(sd: Mapping[str, Tensor], z: Tensor, noises: Optional[Sequence[Tensor]] = None) -> Tensor:
+def generator(sd: Mapping[str, Tensor], z: Tensor, noises: Optional[Sequence[Tensor]] = None, blur_size: Optional[int] = None) -> Tensor:
     """StyleGan2Generator.forward (stylegan2.py:92-101)."""
     feed = _NoiseFeed(noises)
     w = mapping_network(sd, z)
@@ -203,7 +208,7 @@ def generator(sd: Mapping[str, Tensor], z: Tensor, noises: Optional[Sequence[Ten
     x = sd["learned_input"].expand(z.shape[0], -1, -1, -1)
     x, y = generator_block(sd, "blocks.0.", x, w, True, feed)
     for b in range(1, n_blocks):
-        x, rgb = generator_block(sd, f"blocks.{b}.", x, w, False, feed)
+        x, rgb = generator_block(sd, f"blocks.{b}.", x, w, False, feed, blur_size)
         y = nearest_up2(y) + rgb
     return y
 
@@ -223,23 +228,25 @@ def minibatch_stddev(imgs: Tensor, group_size: int = 4) -> Tensor:
     return torch.cat([imgs, plane.to(imgs.dtype)], dim=1)
 
 
-def disc_block(sd: Mapping[str, Tensor], prefix: str, x: Tensor) -> Tensor:
-    """ProgressiveGanDiscriminatorBlock.forward (progressive_gan.py:40-54), out-of-place LeakyReLU."""
+def disc_block(sd: Mapping[str, Tensor], prefix: str, x: Tensor, blur_size: Optional[int] = None) -> Tensor:
+    """ProgressiveGanDiscriminatorBlock.forward (progressive_gan.py:40-54), out-of-place LeakyReLU.  blur_size: both
+    AvgPool2d(2) replaced by Blur(blur_size, down=2) (the pairing of blur_conv_down, nvidia_ops.py:104-123)."""
+    down = avg_pool2 if blur_size is None else (lambda t: blur(t, blur_size, down=2))
     h = bias_leaky_relu(x, None)
     h = F.conv2d(h, sd[prefix + "layers.1.weight"], sd[prefix + "layers.1.bias"], padding=1)
     h = bias_leaky_relu(h, None)
     h = F.conv2d(h, sd[prefix + "layers.3.weight"], sd[prefix + "layers.3.bias"], padding=1)
-    h = avg_pool2(h)
-    s = F.conv2d(avg_pool2(x), sd[prefix + "shortcut.1.weight"], sd[prefix + "shortcut.1.bias"])
+    h = down(h)
+    s = F.conv2d(down(x), sd[prefix + "shortcut.1.weight"], sd[prefix + "shortcut.1.bias"])
     return s + h * sd[prefix + "scale"]
 
 
-def discriminator(sd: Mapping[str, Tensor], imgs: Tensor) -> Tensor:
+def discriminator(sd: Mapping[str, Tensor], imgs: Tensor, blur_size: Optional[int] = None) -> Tensor:
     """ProgressiveGanDiscriminator (progressive_gan.py:57-82) -> logits (N,)."""
-    last = max(int(k.split(".")[0]) for k in sd)
+    last = max(int(k.split(".")[0]) for k in sd if k.split(".")[0].isdigit())
     x = F.conv2d(imgs, sd["0.weight"], sd["0.bias"])
     for b in range(1, last):
-        x = disc_block(sd, f"{b}.", x)
+        x = disc_block(sd, f"{b}.", x, blur_size)
     x = minibatch_stddev(x)
     x = F.conv2d(x, sd[f"{last}.1.weight"], sd[f"{last}.1.bias"], padding=1)
     x = bias_leaky_relu(x, None)

@@ -547,3 +547,92 @@ def test_generators_v1_golden(dev, golden, name):
     e_g, e_g_cpu = total({k: p.grad for k, p in named.items()}), total({k: v.grad for k, v in sc.items()})
     print(f"{name} bf16: image {e_img:.2e} (CPU autocast {e_img_cpu:.2e}), all grads {e_g:.2e} (CPU autocast {e_g_cpu:.2e})")
     assert e_g < max(3e-2, 2.0 * e_g_cpu), (e_g, e_g_cpu)
+
+
+# ------------------------------------------------------------------------------------------
+def test_blur_enabled_discriminator(dev, golden):
+    """SURVEY 8 f1, discriminator side.  (a) blur_size=2: Blur(2, down=2) IS AvgPool2d(2), so the FIR path of the block
+    must reproduce the REFERENCE's discriminator goldens (logits, hinge + R1 value, every parameter gradient through the
+    double backward of upfirdn2d).  (b) blur_size=4: against the oracle's composition in fp64 (no reference model has the
+    blur: parity there is pinned by the pinned ops, not by a reference output)."""
+    from gan_amd.losses import get_loss, get_regularizer
+    from gan_amd.modelling import build_discriminator
+    from oracle import gan_oracle as O
+
+    g = golden("disc")["disc16"]
+    base = g["state"]["0.weight"].shape[0]
+    reals, fakes = g["reals"].to(dev), g["fakes"].to(dev)
+    hinge, r1 = get_loss("hinge"), get_regularizer("r1")
+    # (a)
+    disc = build_discriminator("stylegan2", img_size=16, base_dim=base, blur_size=2)
+    disc.load_state_dict(g["state"], strict=False)  # the Blur buffers are the only extra keys
+    disc = disc.to(dev)
+    r = reals.clone().requires_grad_()
+    d_r = disc(r)
+    assert rel_err(d_r, g["logits_reals"]) < TOL
+    total = hinge.d_loss(d_r, disc(fakes)) + r1(disc, r, fakes, d_r)
+    total.backward()
+    assert math.isclose(float(total), g["hinge_r1"]["value"], rel_tol=1e-5)
+    _check_param_grads(disc, g["hinge_r1"]["grads"], TOL2)
+    # (b)
+    disc = build_discriminator("stylegan2", img_size=16, base_dim=base, blur_size=4)
+    disc.load_state_dict(g["state"], strict=False)
+    disc = disc.to(dev)
+    r = reals.clone().requires_grad_()
+    d_r = disc(r)
+    total = hinge.d_loss(d_r, disc(fakes)) + r1(disc, r, fakes, d_r)
+    total.backward()
+    sd = {k: v.double().requires_grad_(True) for k, v in g["state"].items()}
+    ro = g["reals"].double().requires_grad_(True)
+    o_r = O.discriminator(sd, ro, blur_size=4)
+    want = O.d_loss("hinge", o_r, O.discriminator(sd, g["fakes"].double(), blur_size=4)) + O.r1_penalty(None, ro, None, o_r)
+    want.backward()
+    assert rel_err(d_r, o_r) < TOL and math.isclose(float(total), float(want), rel_tol=1e-5)
+    _check_param_grads(disc, {k: v.grad.float() for k, v in sd.items()}, TOL2)
+
+
+def test_blur_enabled_generator(dev, golden):
+    """SURVEY 8 f1, generator side: StyleGan2Generator(blur_size=3) puts Blur(3) in the `# TODO: blur` slot
+    (stylegan2.py:47); image and every parameter gradient against the oracle's composition in fp64."""
+    from gan_amd.modelling import build_generator
+    from oracle import gan_oracle as O
+    from oracle.detparams import det_state, det_uniform
+    from oracle.tape import RandTape
+
+    gen = build_generator("stylegan2", img_size=16, base_dim=128, blur_size=3)
+    keys = [k for k in gen.state_dict() if not k.endswith("kernel")]
+    shapes = {k: tuple(gen.state_dict()[k].shape) for k in keys}
+    assert "blocks.1.layers.3.scale" in shapes and "blocks.1.layers.5.weight" in shapes  # Blur sits at layers.2
+    state = det_state(shapes, seed=41)
+    gen.load_state_dict(state, strict=False)
+    gen = gen.to(dev)
+    z = det_uniform((4, 128), 431) * 3.0
+    torch.manual_seed(4)
+    with RandTape() as rec:
+        img = gen(z.to(dev))
+    wgt = det_uniform(tuple(img.shape), 432)
+    ((img * wgt.to(dev)).sum() + img.square().mean()).backward()
+    sd = {k: v.double().requires_grad_(True) for k, v in state.items()}
+    img_o = O.generator(sd, z.double(), [t.double() for t in rec.tape], blur_size=3)
+    ((img_o * wgt.double()).sum() + img_o.square().mean()).backward()
+    assert rel_err(img, img_o) < TOL
+    named = dict(gen.named_parameters())
+    for k, v in sd.items():
+        assert rel_err(named[k].grad, v.grad) < TOL, (k, rel_err(named[k].grad, v.grad))
+
+
+def test_trainer_runs_stylegan_v1_recipe(dev):
+    """README.md:59 recipe with --model stylegan (v1 generator + the shared discriminator, hinge + R1, bf16): three
+    iterations through the Trainer, graph replay included, finite losses."""
+    from gan_amd.train_celeba import TrainConfig, Trainer
+
+    torch.manual_seed(0)
+    cfg = TrainConfig(model="stylegan", img_size=32, gen_kwargs={"base_dim": 32}, disc_kwargs={"base_dim": 16}, method="hinge", regularizer="r1",
+                      batch_size=8, optimizer="Adam", optimizer_kwargs={"betas": [0.0, 0.9]}, lr=2e-4, device="cuda", mixed_precision=True,
+                      channels_last=True, hip_graph=True, graph_warmup=1)
+    tr = Trainer(cfg, dev)
+    reals = torch.randn(8, 3, 32, 32, device=dev)
+    for _ in range(4):
+        logs = tr.train_step(lambda: reals.clone())
+    assert tr._graph is not None
+    assert all(bool(torch.isfinite(v).all()) for v in logs.values()), logs
