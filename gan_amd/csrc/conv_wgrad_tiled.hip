@@ -215,6 +215,7 @@ __global__ void __launch_bounds__(TW_THREADS) conv_wgrad_tiled_k(const TWArgs p)
 #pragma unroll 1
             for (int ks = 0; ks < 4; ++ks) {
                 if (KS == 1 && (ks % 3) != wave) continue;
+                if (KS == 2 && wave == 2) continue;  // two kernel rows: the third consumer wave only keeps the barriers
                 const int Plo = ks * 32 + 4 * g + q, Phi = Plo + 16;
                 bf16x8 a[4];
 #pragma unroll
@@ -237,7 +238,7 @@ __global__ void __launch_bounds__(TW_THREADS) conv_wgrad_tiled_k(const TWArgs p)
             }
         }
         // ---- partial tile -> workspace slice s, final layout [tap][Cout][Cin] (3x3: one tap row per wave)
-        if (KS != 1) {
+        if (KS != 1 && wave < KS) {
             float* __restrict__ slice = p.ws + (int64_t)s * KS * KS * p.Cout * p.Cin;
 #pragma unroll
             for (int dx = 0; dx < NT; ++dx) {
@@ -362,7 +363,8 @@ TiledPlan plan_tiled(int N, int Ho, int Wo, int Cin, int Cout, int ks) {
 
 // floats of workspace gan_conv2d_wgrad_tiled needs for this shape (0: shape not served by it)
 int64_t gan_wgrad_tiled_workspace(int N, int Ho, int Wo, int Cin, int Cout, int kh, int kw, int py, int px) {
-    if (kh != kw || (kh != 1 && kh != 3) || py != (kh - 1) / 2 || px != py) return 0;
+    // 1x1 / 3x3 "same" convolutions, and 2x2 valid ones (stride-2 layers folded by space-to-depth: gan_space_to_depth)
+    if (kh != kw || px != py || !((kh == 1 && py == 0) || (kh == 3 && py == 1) || (kh == 2 && py == 0))) return 0;
     if ((Cin & 7) || (Cout & 7)) return 0;
     if ((int64_t)N * Ho * Wo * (Cin > Cout ? Cin : Cout) >= (1LL << 30)) return 0;  // 32-bit byte offsets, INV past the end
     const TiledPlan pl = plan_tiled(N, Ho, Wo, Cin, Cout, kh);
@@ -398,6 +400,11 @@ int gan_conv2d_wgrad_tiled(const void* x, const void* gy, const DwOut& dwo, cons
         else if (pl.tw_log2 == 4) TW_LAUNCH(3, 4, 3, 0);
         else if (pl.tw_log2 == 3) TW_LAUNCH(3, 3, 3, 1);
         else TW_LAUNCH(3, 2, 2, 3);
+    } else if (kh == 2) {
+        if (pl.tw_log2 == 5) TW_LAUNCH(2, 5, 2, 0);
+        else if (pl.tw_log2 == 4) TW_LAUNCH(2, 4, 3, 0);
+        else if (pl.tw_log2 == 3) TW_LAUNCH(2, 3, 3, 1);
+        else TW_LAUNCH(2, 2, 2, 3);
     } else {
         if (pl.tw_log2 == 5) TW_LAUNCH(1, 5, 2, 0);
         else if (pl.tw_log2 == 4) TW_LAUNCH(1, 4, 3, 0);

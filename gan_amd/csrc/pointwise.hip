@@ -975,6 +975,74 @@ extern "C" int gan_mbstd_concat_adj(const void* g, void* gx, float* gstat, int N
 }
 
 // =========================================================================================
+// Space-to-depth with zero padding and its adjoint: what turns a stride-2 convolution (DCGAN's 4x4 / stride 2 / pad 1
+// layers, modelling/dcgan.py:21-29,50-60) into a stride-1 convolution with no wasted products.
+//   s2d: out[n][by][bx][(dy*2+dx)*C + c] = x[n][2by+dy-pad][2bx+dx-pad][c]  (zero outside), out: [N][Hb][Wb][4C]
+//   d2s: out[n][iy][ix][c] = in[n][(iy+pad)/2][(ix+pad)/2][((iy+pad)%2*2 + (ix+pad)%2)*C + c],  in: [N][Hb][Wb][4C]
+// Both are gathers; each is the other's adjoint.
+// =========================================================================================
+template <typename T, int V>
+__global__ void __launch_bounds__(TPB) s2d_k(const T* __restrict__ x, T* __restrict__ out, int H, int W, int C, int Hb, int Wb, int pad,
+                                             int64_t total, int to_depth) {
+    const int64_t idx = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (idx >= total) return;
+    const int cv = C / V;
+    if (to_depth) {  // idx over out: [n][by][bx][d][c/V]
+        const int c = (int)(idx % cv) * V;
+        int64_t r = idx / cv;
+        const int d = (int)(r % 4);
+        r /= 4;
+        const int bx = (int)(r % Wb);
+        r /= Wb;
+        const int by = (int)(r % Hb);
+        const int64_t n = r / Hb;
+        const int iy = 2 * by + (d >> 1) - pad, ix = 2 * bx + (d & 1) - pad;
+        float v[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) v[e] = 0.f;
+        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) load_f<T, V>(x + ((n * H + iy) * W + ix) * C + c, v);
+        store_f<T, V>(out + idx * V, v);
+    } else {  // idx over out: [n][iy][ix][c/V]
+        const int c = (int)(idx % cv) * V;
+        int64_t r = idx / cv;
+        const int ix = (int)(r % W);
+        r /= W;
+        const int iy = (int)(r % H);
+        const int64_t n = r / H;
+        const int py = iy + pad, px = ix + pad;
+        const int d = (py & 1) * 2 + (px & 1);
+        float v[V];
+        load_f<T, V>(x + (((n * Hb + (py >> 1)) * Wb + (px >> 1)) * 4 + d) * C + c, v);
+        store_f<T, V>(out + idx * V, v);
+    }
+}
+
+extern "C" int gan_space_to_depth(const void* x, void* out, int N, int H, int W, int C, int pad, int to_depth, int dtype, gan_stream_t stream) {
+    GAN_CHECK_ARG(N >= 0 && H > 0 && W > 0 && C > 0 && pad >= 0, "space_to_depth: bad shape");
+    GAN_CHECK_ARG(((H + 2 * pad) & 1) == 0 && ((W + 2 * pad) & 1) == 0, "space_to_depth: padded size %dx%d must be even", H + 2 * pad, W + 2 * pad);
+    GAN_CHECK_ARG(dtype == GAN_F32 || dtype == GAN_BF16, "space_to_depth: bad dtype %d", dtype);
+    if (N == 0) return GAN_OK;
+    GAN_CHECK_ARG(x && out, "space_to_depth: null pointer");
+    const int Hb = (H + 2 * pad) / 2, Wb = (W + 2 * pad) / 2;
+    const int VV = dtype == GAN_F32 ? 4 : 8;
+    const bool vec = (C % VV) == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)out % 16) == 0;
+    const int64_t elems = to_depth ? (int64_t)N * Hb * Wb * 4 * C : (int64_t)N * H * W * C;
+    const int64_t total = vec ? elems / VV : elems;
+    const int64_t blocks = ceil_div64(total, TPB);
+    GAN_CHECK_ARG(blocks < (1LL << 31), "space_to_depth: tensor too large");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == GAN_F32) {
+        if (vec) hipLaunchKernelGGL((s2d_k<float, 4>), dim3((unsigned)blocks), dim3(TPB), 0, st, (const float*)x, (float*)out, H, W, C, Hb, Wb, pad, total, to_depth);
+        else hipLaunchKernelGGL((s2d_k<float, 1>), dim3((unsigned)blocks), dim3(TPB), 0, st, (const float*)x, (float*)out, H, W, C, Hb, Wb, pad, total, to_depth);
+    } else {
+        if (vec) hipLaunchKernelGGL((s2d_k<bf16, 8>), dim3((unsigned)blocks), dim3(TPB), 0, st, (const bf16*)x, (bf16*)out, H, W, C, Hb, Wb, pad, total, to_depth);
+        else hipLaunchKernelGGL((s2d_k<bf16, 1>), dim3((unsigned)blocks), dim3(TPB), 0, st, (const bf16*)x, (bf16*)out, H, W, C, Hb, Wb, pad, total, to_depth);
+    }
+    GAN_CHECK_LAUNCH("space_to_depth");
+    return GAN_OK;
+}
+
+// =========================================================================================
 // EMA lerp over one flat fp32 arena (reference: utils.py:95-96)
 // =========================================================================================
 __global__ void __launch_bounds__(TPB) ema_lerp_k(float* __restrict__ ema, const float* __restrict__ p, int64_t n4,

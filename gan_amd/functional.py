@@ -1125,6 +1125,50 @@ class MbstdBwdFn(Function):
         return gx2, (ggstat.to(ctx.gstat_dtype) if ggstat is not None else None), None
 
 
+def _raw_s2d(x: Tensor, pad: int, to_depth: bool, h: int, w: int, c: int) -> Tensor:
+    """to_depth: x (N, C, H, W) -> (N, 4C, (H+2p)/2, (W+2p)/2); else x (N, 4C, Hb, Wb) -> (N, C, H, W) (h, w, c = the un-folded size)."""
+    require_gpu(x)
+    xc = as_cl(x.detach())
+    n = xc.shape[0]
+    if (h + 2 * pad) % 2 or (w + 2 * pad) % 2:
+        raise _lib.GanAmdError(f"space_to_depth: padded size {h + 2 * pad}x{w + 2 * pad} must be even")
+    shape = (n, 4 * c, (h + 2 * pad) // 2, (w + 2 * pad) // 2) if to_depth else (n, c, h, w)
+    out = _empty_like_cl(xc, shape)
+    check(_run("space_to_depth", 0, _nbytes(xc, out),
+               lambda: _lib.load().gan_space_to_depth(ptr(xc), ptr(out), n, h, w, c, pad, int(to_depth), dtype_code(xc), stream_of(xc)), (n, c, h, w)),
+          "gan_space_to_depth")
+    return out
+
+
+class SpaceToDepthFn(Function):
+    """S2D_p: zero-pad by p, fold each 2x2 pixel block into the channels (channel (dy*2+dx)*C + c).  Linear; adjoint = DepthToSpaceFn."""
+
+    @staticmethod
+    def forward(ctx, x, pad):
+        n, c, h, w = x.shape
+        ctx.cfg = (pad, h, w, c)
+        return _raw_s2d(x, pad, True, h, w, c)
+
+    @staticmethod
+    def backward(ctx, g):
+        pad, h, w, c = ctx.cfg
+        return DepthToSpaceFn.apply(g, pad, h, w), None
+
+
+class DepthToSpaceFn(Function):
+    """The adjoint of S2D_p: unfold the channels into 2x2 pixel blocks and crop p from every side -> (N, C, h, w)."""
+
+    @staticmethod
+    def forward(ctx, y, pad, h, w):
+        c = y.shape[1] // 4
+        ctx.pad = pad
+        return _raw_s2d(y, pad, False, h, w, c)
+
+    @staticmethod
+    def backward(ctx, g):
+        return SpaceToDepthFn.apply(g, ctx.pad), None, None, None
+
+
 class InstNormAffineFn(Function):
     """y = lrelu_slope( instance_norm(x) * gamma[n, c] + beta[n, c] ): AdaIN (modelling/common.py:13-16; F.instance_norm:
     biased variance over H x W, eps 1e-5) with the LeakyReLU that follows it in the StyleGAN generator block

@@ -105,8 +105,18 @@ def get_act(act: str):
     return dict(none=nn.Identity, relu=nn.ReLU, leaky_relu=partial(LeakyReLU, negative_slope=0.2), tanh=nn.Tanh)[act]()
 
 
+def _fold_weight(weight: Tensor) -> Tensor:
+    """(Co, C, 2m, 2m) -> (Co, 4C, m, m): the stride-2 kernel as a stride-1 kernel over space-to-depth input, input channel
+    (dy*2+dx)*C + c and tap (by, bx) <- tap (2by+dy, 2bx+dx).  A permutation of the parameter (differentiable view + copy)."""
+    co, c, k, _ = weight.shape
+    m = k // 2
+    return weight.reshape(co, c, m, 2, m, 2).permute(0, 3, 5, 1, 2, 4).reshape(co, 4 * c, m, m)
+
+
 class _StridedConv2d(nn.Conv2d):
-    """Conv2d(stride 2) as a stride-1 MFMA correlation followed by keeping every second sample."""
+    """Conv2d(k, stride 2, p).  Even k with even padded size (DCGAN's 4x4 / 2 / 1, dcgan.py:21-29): space-to-depth + a
+    stride-1 (k/2 x k/2) valid convolution -- every product the MFMA kernel forms is one the strided convolution needs.
+    Otherwise: stride-1 correlation followed by keeping every second sample."""
 
     def forward(self, x: Tensor) -> Tensor:
         if self.stride == (1, 1):
@@ -114,6 +124,10 @@ class _StridedConv2d(nn.Conv2d):
         if self.stride != (2, 2):
             raise GF._lib.GanAmdError("gan_amd strided Conv2d supports stride 1 or 2")
         x = to_act(x)
+        k, p = self.kernel_size[0], self.padding[0]
+        if k % 2 == 0 and k == self.kernel_size[1] and p == self.padding[1] and (x.shape[2] + 2 * p) % 2 == 0 and (x.shape[3] + 2 * p) % 2 == 0:
+            xs = GF.SpaceToDepthFn.apply(x, p)
+            return GF.conv_bias_act(xs, _fold_weight(self.weight), self.bias, 0)
         y = GF.Conv2dFn.apply(x, self.weight, self.padding[0], self.padding[1])
         y = GF.upfirdn2d(y, torch.ones(1, 1, device=x.device), 1, 2, 0, 0, 0, 0)
         return GF.affine_act(y, b=self.bias) if self.bias is not None else y
@@ -131,6 +145,14 @@ class _ConvTranspose2d(nn.ConvTranspose2d):
             raise GF._lib.GanAmdError("gan_amd ConvTranspose2d supports stride 1 or 2, groups 1, dilation 1")
         x = to_act(x)
         full = k - 1 - p
+        if st == 2 and k % 2 == 0 and op == 0 and k == self.kernel_size[1]:
+            # the adjoint of the strided convolution above: input gradient of the folded valid convolution (a stride-1
+            # correlation with the flipped, transposed folded weights), then depth-to-space with the crop
+            n, _, h, w = x.shape
+            m = k // 2
+            y4 = GF.Conv2dDgradFn.apply(x, _fold_weight(self.weight), 0, 0)  # (N, 4 Cout, h + m - 1, w + m - 1)
+            y = GF.DepthToSpaceFn.apply(y4, p, 2 * (h + m - 1) - 2 * p, 2 * (w + m - 1) - 2 * p)
+            return GF.affine_act(y, b=self.bias) if self.bias is not None else y
         if st == 2:
             x = GF.upfirdn2d(x, torch.ones(1, 1, device=x.device), 2, 1, full, full - 1 + op, full, full - 1 + op)
             full = 0

@@ -223,6 +223,14 @@ int gan_mbstd_bwd2(const void* x, const float* gstat, const void* u, void* gx2, 
 int gan_mbstd_concat(const void* x, const float* stat, void* out, int N, int G, int64_t HW, int C, int dtype, gan_stream_t stream);
 int gan_mbstd_concat_adj(const void* g, void* gx, float* gstat, int N, int G, int64_t HW, int C, int dtype, gan_stream_t stream);
 
+/* ---- stride-2 convolutions as stride-1 convolutions ------------------------------------------------------------
+ * replaces the stride of nn.Conv2d(k, 2, p) / nn.ConvTranspose2d(k, 2, p) with even k in DCGAN (modelling/dcgan.py:21-29,
+ * 50-60 through conv_norm_act, modelling/common.py:46-70): Conv_s2(x; W) = ValidConv_{k/2}(S2D_p(x); W') with
+ *   S2D_p (to_depth = 1): out [N][(H+2p)/2][(W+2p)/2][4C], channel (dy*2+dx)*C + c <- x[n][2by+dy-p][2bx+dx-p][c], 0 outside
+ *   its adjoint (to_depth = 0): out [N][H][W][C] from in [N][(H+2p)/2][(W+2p)/2][4C]  (ConvTranspose2d's last stage).
+ * H, W, C always describe the un-folded tensor. */
+int gan_space_to_depth(const void* x, void* out, int N, int H, int W, int C, int pad, int to_depth, int dtype, gan_stream_t stream);
+
 /* ---- AdaIN / LayerNorm2d (the StyleGAN-v1 and Progressive-GAN generators) ------------------------------------
  * replaces AdaIN.forward              modelling/common.py:13-16   F.instance_norm(x) * (style_w(w) + 1) + style_b(w)
  *          LayerNorm2d.forward        modelling/common.py:20-24   nn.LayerNorm over the channels of each pixel

@@ -779,3 +779,43 @@ def test_flat_adam_matches_torch(dev, name, kwargs):
     assert set(sd["state"][0].keys()) == {"step", "exp_avg", "exp_avg_sq"} and float(sd["state"][0]["step"]) == 6.0
     assert isinstance(make_optimizer("SGD", net, 0.1, {"momentum": 0.9}), torch.optim.SGD)
     assert isinstance(make_optimizer("Adam", net, 0.1, {"amsgrad": True}), torch.optim.Adam)
+
+
+# ------------------------------------------------------------------------------------------
+# stride-2 layers folded by space-to-depth (DCGAN, dcgan.py:21-29,50-60): N, C, H, W, Cout, k, p
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", [(4, 3, 64, 64, 64, 4, 1), (4, 64, 32, 32, 128, 4, 1), (3, 128, 16, 16, 256, 4, 1), (5, 256, 8, 8, 512, 4, 1),
+                                  (2, 24, 10, 14, 40, 2, 0), (2, 16, 12, 12, 8, 6, 2)])
+def test_strided_conv_and_transpose_via_space_to_depth(dev, case, dtype):
+    """_StridedConv2d / _ConvTranspose2d (stride 2, even kernel): space-to-depth + a stride-1 valid convolution (its
+    weight gradient on the tiled kernel's 2x2 variant) and the adjoint pair, against F.conv2d / F.conv_transpose2d in fp64:
+    forward, input / weight / bias gradients, and a second-order term (WGAN-GP differentiates the discriminator twice)."""
+    from gan_amd.modelling.common import _ConvTranspose2d, _StridedConv2d
+
+    n, c, h, w, cout, k, p = case
+    tol, tol2 = (TOL32, TOL32_2) if dtype == torch.float32 else (TOLBF, 3 * TOLBF)
+    torch.manual_seed(3)
+    for transposed in (False, True):
+        if transposed:
+            mod = _ConvTranspose2d(cout, c, k, 2, p).to(dev)   # maps cout -> c channels, (h/2) -> h
+            x = torch.randn(n, cout, h // 2, w // 2).to(dtype)
+        else:
+            mod = _StridedConv2d(c, cout, k, 2, p).to(dev)
+            x = torch.randn(n, c, h, w).to(dtype)
+        wr = mod.weight.detach().double().cpu().requires_grad_(True)
+        br = mod.bias.detach().double().cpu().requires_grad_(True)
+        xr = x.double().requires_grad_(True)
+        xg = x.to(dev).requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=dtype == torch.bfloat16):
+            y = mod(xg)
+        ref = F.conv_transpose2d(xr, wr, br, stride=2, padding=p) if transposed else F.conv2d(xr, wr, br, stride=2, padding=p)
+        assert y.shape == ref.shape and rel_err(y, ref) < tol, (case, transposed, rel_err(y, ref))
+        wgt = torch.randn(ref.shape)
+        g = torch.autograd.grad((y.float() * wgt.to(dev)).sum(), [xg, mod.weight, mod.bias], create_graph=True)
+        gr = torch.autograd.grad((ref * wgt.double()).sum(), [xr, wr, br], create_graph=True)
+        for a, b, nm in zip(g, gr, ("x", "weight", "bias")):
+            assert rel_err(a, b) < tol2, (case, transposed, nm, rel_err(a, b))
+        # second order: d/dw of |dL/dx|^2 (bilinear map: exercises conv <-> dgrad <-> wgrad through the fold)
+        (g2,) = torch.autograd.grad(g[0].float().square().sum(), mod.weight)
+        (g2r,) = torch.autograd.grad(gr[0].square().sum(), wr)
+        assert rel_err(g2, g2r) < 3 * tol2, (case, transposed, rel_err(g2, g2r))
