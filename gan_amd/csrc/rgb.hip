@@ -1,0 +1,303 @@
+// The image boundary of the discriminator (gfx950): nn.Conv2d(img_channels = 3, base_dim, 1) (progressive_gan.py:61)
+// and its two adjoints, as HBM-streaming kernels that read / write the 3-channel tensor as it is.
+//
+// Round 1 padded the image to 16 channels (gan_pad_channels: 5.3x its bytes written) and ran the generic thin kernels on
+// the padded copy: per discriminator pass at 256 x 256, batch 256 that moved 1.7 GB where 0.7 GB is compulsory, and the
+// fp32 reals took a cast + layout pass in front.  Here
+//   fwd  : y[n][p][co]  = act( sum_c x[n, c, p] * W[co][c] + b[co] )        x: any strides, fp32 or bf16; y: [N][HW][Cout]
+//   dgrad: gx[n][p][c]  = sum_co gy[n][p][co] * W[co][c]                      gx: [N][HW][Cin] (channels-last, Cin <= 4)
+//   wgrad: dw[co][c]    = sum_{n,p} gy[n][p][co] * x[n, c, p]                 fp32, two stages through a caller workspace
+// All three are bilinear in their two tensor arguments and closed under differentiation (fwd <-> dgrad <-> wgrad), so
+// R1's double backward through the first layer runs on them too.
+#include "common.h"
+
+namespace {
+
+constexpr int RTPB = 256;
+constexpr int RGB_MAXC = 4;       // image channels
+constexpr int RGB_WG_BLOCKS = 1024;
+constexpr unsigned RGB_FWD_PX = 4;  // pixels per thread of the forward kernel
+
+template <typename T>
+__device__ __forceinline__ float ldf(const T* p) { return (float)*p; }
+
+// Element offset of pixel p (0 .. HW) of sample n in the strided image.  `lin`: sh == W * sw (dense NCHW and
+// channels-last both are), so the pixel index itself is the spatial offset and no division is needed.
+__device__ __forceinline__ int64_t rgb_xoff(unsigned n, unsigned p, int64_t sn, int64_t sh, int64_t sw, unsigned W, bool lin) {
+    if (lin) return (int64_t)n * sn + (int64_t)p * sw;
+    const unsigned h = p / W, w = p - h * W;
+    return (int64_t)n * sn + (int64_t)h * sh + (int64_t)w * sw;
+}
+
+// fwd: one thread = one pixel x 8 output channels; CV = Cout / 8 consecutive lanes share a pixel, so a wave's 16-byte
+// stores are one contiguous run.  grid.y = sample.  Weights sit in LDS padded to 4 input channels (one ds_read_b128
+// per output channel, the same address for every lane: a broadcast).
+template <typename TI, typename TO, int CV>
+__global__ void __launch_bounds__(RTPB) rgb_fwd_k(const TI* __restrict__ x, int64_t sn, int64_t sc, int64_t sh, int64_t sw, unsigned W, int lin,
+                                                  const float* __restrict__ wgt, const float* __restrict__ bias, TO* __restrict__ y, unsigned HW,
+                                                  int Cin, float slope) {
+    constexpr int COUT = CV * 8;
+    __shared__ float4 wl[COUT];
+    __shared__ float bl[COUT];
+    for (int i = threadIdx.x; i < COUT; i += RTPB) {
+        float t[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < Cin; ++c) t[c] = wgt[i * Cin + c];
+        wl[i] = make_float4(t[0], t[1], t[2], t[3]);
+        bl[i] = bias ? bias[i] : 0.f;
+    }
+    __syncthreads();
+    // a thread keeps the weights of its 8 output channels in registers and walks RGB_FWD_PX pixels
+    const int c8 = (int)(threadIdx.x % CV) * 8;
+    const unsigned lp = threadIdx.x / CV;
+    constexpr unsigned PPB = RTPB / CV;
+    float4 wr[8];
+    float br[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        wr[j] = wl[c8 + j];
+        br[j] = bl[c8 + j];
+    }
+    const unsigned n = blockIdx.y;
+#pragma unroll
+    for (unsigned it = 0; it < RGB_FWD_PX; ++it) {
+        const unsigned p = (blockIdx.x * RGB_FWD_PX + it) * PPB + lp;
+        if (p >= HW) break;
+        const TI* __restrict__ xp = x + rgb_xoff(n, p, sn, sh, sw, W, lin);
+        float xv[RGB_MAXC];
+#pragma unroll
+        for (int c = 0; c < RGB_MAXC; ++c) xv[c] = c < Cin ? ldf(xp + c * sc) : 0.f;
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            o[j] = lrelu_f(fmaf(xv[0], wr[j].x, fmaf(xv[1], wr[j].y, fmaf(xv[2], wr[j].z, fmaf(xv[3], wr[j].w, br[j])))), slope);
+        TO* __restrict__ yp = y + ((int64_t)n * HW + p) * COUT + c8;
+        if constexpr (sizeof(TO) == 2) {
+            store_f<TO, 8>(yp, o);
+        } else {
+            const float lo[4] = {o[0], o[1], o[2], o[3]}, hi[4] = {o[4], o[5], o[6], o[7]};
+            store_f<TO, 4>(yp, lo);
+            store_f<TO, 4>(yp + 4, hi);
+        }
+    }
+}
+
+// dgrad: CV consecutive lanes share a pixel, each takes one 16-byte (8-channel) chunk of its gradient -- a wave's loads
+// are one contiguous run -- and the partial dot products are folded with xor-shuffles.  Results go through LDS so that
+// the Cin-channel output (6 bytes per pixel for RGB in bf16) leaves as contiguous 4-byte stores.
+template <typename T, int CV>
+__global__ void __launch_bounds__(RTPB) rgb_dgrad_k(const T* __restrict__ gy, const float* __restrict__ wgt, T* __restrict__ gx, int64_t NP, int Cin) {
+    constexpr int COUT = CV * 8, PPB = RTPB / CV;  // pixels per workgroup
+    __shared__ float4 wl[COUT];
+    __shared__ __attribute__((aligned(16))) T ol[PPB * RGB_MAXC];
+    for (int i = threadIdx.x; i < COUT; i += RTPB) {
+        float t[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < Cin; ++c) t[c] = wgt[i * Cin + c];
+        wl[i] = make_float4(t[0], t[1], t[2], t[3]);
+    }
+    __syncthreads();
+    const int lp = threadIdx.x / CV, ch = threadIdx.x % CV;
+    const int64_t pix0 = (int64_t)blockIdx.x * PPB;
+    const int64_t pix = pix0 + lp;
+    float acc[RGB_MAXC] = {0.f, 0.f, 0.f, 0.f};
+    if (pix < NP) {
+        float g[8];
+        if constexpr (sizeof(T) == 2) {
+            load_f<T, 8>(gy + pix * COUT + ch * 8, g);
+        } else {
+            float lo[4], hi[4];
+            load_f<T, 4>(gy + pix * COUT + ch * 8, lo);
+            load_f<T, 4>(gy + pix * COUT + ch * 8 + 4, hi);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { g[j] = lo[j]; g[4 + j] = hi[j]; }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float4 w4 = wl[ch * 8 + j];
+            acc[0] = fmaf(g[j], w4.x, acc[0]); acc[1] = fmaf(g[j], w4.y, acc[1]);
+            acc[2] = fmaf(g[j], w4.z, acc[2]); acc[3] = fmaf(g[j], w4.w, acc[3]);
+        }
+    }
+#pragma unroll
+    for (int off = 1; off < CV; off <<= 1)
+#pragma unroll
+        for (int c = 0; c < RGB_MAXC; ++c) acc[c] += __shfl_xor(acc[c], off);
+    if (ch == 0)
+        for (int c = 0; c < Cin; ++c) ol[lp * Cin + c] = (T)acc[c];
+    __syncthreads();
+    // the workgroup's PPB * Cin outputs are contiguous in gx (channels-last, Cin channels)
+    int64_t live = NP - pix0;
+    if (live > PPB) live = PPB;
+    const int nel = (int)live * Cin;
+    T* __restrict__ dst = gx + pix0 * Cin;
+    constexpr int EPW = 4 / sizeof(T);  // elements per 4-byte word
+    if ((pix0 * Cin * (int64_t)sizeof(T)) % 4 == 0) {
+        for (int i = threadIdx.x; i < nel / EPW; i += RTPB) reinterpret_cast<uint32_t*>(dst)[i] = reinterpret_cast<const uint32_t*>(ol)[i];
+        for (int i = (nel / EPW) * EPW + threadIdx.x; i < nel; i += RTPB) dst[i] = ol[i];
+    } else {
+        for (int i = threadIdx.x; i < nel; i += RTPB) dst[i] = ol[i];
+    }
+}
+
+// wgrad stage 1: a workgroup walks pixels p = block, block + grid, ...; a thread owns one pixel at a time and keeps Cout x Cin
+// partial sums for ONE 8-channel chunk of Cout (blockIdx.y), folded over the workgroup with shuffles + LDS.
+template <typename TX, typename TG>
+__global__ void __launch_bounds__(RTPB) rgb_wgrad_k(const TX* __restrict__ x, int64_t sn, int64_t sc, int64_t sh, int64_t sw, unsigned W, int lin,
+                                                    const TG* __restrict__ gy, float* __restrict__ ws, unsigned NP, unsigned HW, int Cin, int Cout) {
+    __shared__ float red[RTPB / 64][8 * RGB_MAXC];
+    const int c8 = blockIdx.y * 8;
+    float acc[8][RGB_MAXC];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int c = 0; c < RGB_MAXC; ++c) acc[j][c] = 0.f;
+    for (unsigned pix = blockIdx.x * RTPB + threadIdx.x; pix < NP; pix += gridDim.x * RTPB) {
+        const unsigned n = pix / HW, p = pix - n * HW;
+        const TX* __restrict__ xp = x + rgb_xoff(n, p, sn, sh, sw, W, lin);
+        float xv[RGB_MAXC];
+#pragma unroll
+        for (int c = 0; c < RGB_MAXC; ++c) xv[c] = c < Cin ? ldf(xp + c * sc) : 0.f;
+        float g[8];
+        if constexpr (sizeof(TG) == 2) {
+            load_f<TG, 8>(gy + (int64_t)pix * Cout + c8, g);
+        } else {
+            float lo[4], hi[4];
+            load_f<TG, 4>(gy + (int64_t)pix * Cout + c8, lo);
+            load_f<TG, 4>(gy + (int64_t)pix * Cout + c8 + 4, hi);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { g[j] = lo[j]; g[4 + j] = hi[j]; }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int c = 0; c < RGB_MAXC; ++c) acc[j][c] = fmaf(g[j], xv[c], acc[j][c]);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int c = 0; c < RGB_MAXC; ++c) {
+            float v = acc[j][c];
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+            if (lane == 0) red[wave][j * RGB_MAXC + c] = v;
+        }
+    __syncthreads();
+    if (threadIdx.x < 8 * RGB_MAXC) {
+        float t = 0.f;
+        for (int wv = 0; wv < RTPB / 64; ++wv) t += red[wv][threadIdx.x];
+        const int j = threadIdx.x / RGB_MAXC, c = threadIdx.x % RGB_MAXC;
+        if (c < Cin) ws[((int64_t)blockIdx.x * Cout + c8 + j) * Cin + c] = t;
+    }
+}
+
+// stage 2: dw[co][c] = sum over the partials of the nb workgroups (deterministic order)
+__global__ void __launch_bounds__(64) rgb_wgrad_fold_k(const float* __restrict__ ws, float* __restrict__ dw, int nb, int L) {
+    const int e = blockIdx.x;  // one wave per element
+    float t = 0.f;
+    for (int b = threadIdx.x; b < nb; b += 64) t += ws[(int64_t)b * L + e];
+    for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off);
+    if (threadIdx.x == 0) dw[e] = t;
+}
+
+bool rgb_shape_ok(int Cin, int Cout) { return Cin >= 1 && Cin <= RGB_MAXC && Cout >= 8 && Cout <= 64 && (Cout & 7) == 0; }
+
+}  // namespace
+
+extern "C" int gan_rgb_conv1x1_fwd(const void* x, int x_dtype, int64_t sn, int64_t sc, int64_t sh, int64_t sw, const float* w, const float* bias,
+                                   void* y, int y_dtype, int N, int Cin, int H, int W, int Cout, float slope, gan_stream_t stream) {
+    GAN_CHECK_ARG(N >= 0 && H > 0 && W > 0, "rgb_conv1x1_fwd: bad shape");
+    GAN_CHECK_ARG(rgb_shape_ok(Cin, Cout), "rgb_conv1x1_fwd: serves Cin <= 4 and Cout a multiple of 8 up to 64 (got %d -> %d)", Cin, Cout);
+    GAN_CHECK_ARG((x_dtype == GAN_F32 || x_dtype == GAN_BF16) && (y_dtype == GAN_F32 || y_dtype == GAN_BF16), "rgb_conv1x1_fwd: bad dtype");
+    if (N == 0) return GAN_OK;
+    GAN_CHECK_ARG(x && w && y && ((uintptr_t)y % 16) == 0, "rgb_conv1x1_fwd: null or unaligned pointer");
+    const int64_t HW = (int64_t)H * W;
+    GAN_CHECK_ARG(HW * (Cout / 8) < (1LL << 31) && N <= 65535, "rgb_conv1x1_fwd: tensor too large for the grid");
+    const int CV = Cout / 8;
+    GAN_CHECK_ARG(CV == 1 || CV == 2 || CV == 4 || CV == 8, "rgb_conv1x1_fwd: Cout must be 8, 16, 32 or 64");
+    const dim3 grid((unsigned)ceil_div64(HW * CV, (int64_t)RTPB * RGB_FWD_PX), (unsigned)N);
+    const int lin = sh == (int64_t)W * sw;
+    hipStream_t st = (hipStream_t)stream;
+#define RGB_FWD3(TI, TO, CV_) \
+    hipLaunchKernelGGL((rgb_fwd_k<TI, TO, CV_>), grid, dim3(RTPB), 0, st, (const TI*)x, sn, sc, sh, sw, (unsigned)W, lin, w, bias, (TO*)y, (unsigned)HW, Cin, slope)
+#define RGB_FWD(TI, TO)                     \
+    do {                                    \
+        if (CV == 1) RGB_FWD3(TI, TO, 1);   \
+        else if (CV == 2) RGB_FWD3(TI, TO, 2); \
+        else if (CV == 4) RGB_FWD3(TI, TO, 4); \
+        else RGB_FWD3(TI, TO, 8);           \
+    } while (0)
+    if (x_dtype == GAN_F32 && y_dtype == GAN_F32) RGB_FWD(float, float);
+    else if (x_dtype == GAN_F32) RGB_FWD(float, bf16);
+    else if (y_dtype == GAN_F32) RGB_FWD(bf16, float);
+    else RGB_FWD(bf16, bf16);
+#undef RGB_FWD
+#undef RGB_FWD3
+    GAN_CHECK_LAUNCH("rgb_conv1x1_fwd");
+    return GAN_OK;
+}
+
+extern "C" int gan_rgb_conv1x1_dgrad(const void* gy, const float* w, void* gx, int64_t NP, int Cin, int Cout, int dtype, gan_stream_t stream) {
+    GAN_CHECK_ARG(NP >= 0, "rgb_conv1x1_dgrad: bad shape");
+    GAN_CHECK_ARG(rgb_shape_ok(Cin, Cout), "rgb_conv1x1_dgrad: serves Cin <= 4 and Cout a multiple of 8 up to 64 (got %d <- %d)", Cin, Cout);
+    GAN_CHECK_ARG(dtype == GAN_F32 || dtype == GAN_BF16, "rgb_conv1x1_dgrad: bad dtype %d", dtype);
+    if (NP == 0) return GAN_OK;
+    GAN_CHECK_ARG(gy && w && gx && ((uintptr_t)gy % 16) == 0, "rgb_conv1x1_dgrad: null or unaligned pointer");
+    const int CV = Cout / 8;
+    GAN_CHECK_ARG(CV == 1 || CV == 2 || CV == 4 || CV == 8, "rgb_conv1x1_dgrad: Cout must be 8, 16, 32 or 64");
+    const int64_t blocks = ceil_div64(NP, RTPB / CV);
+    GAN_CHECK_ARG(blocks < (1LL << 31), "rgb_conv1x1_dgrad: tensor too large");
+    hipStream_t st = (hipStream_t)stream;
+#define RGB_DG3(T_, CV_) hipLaunchKernelGGL((rgb_dgrad_k<T_, CV_>), dim3((unsigned)blocks), dim3(RTPB), 0, st, (const T_*)gy, w, (T_*)gx, NP, Cin)
+#define RGB_DG(T_)                   \
+    do {                             \
+        if (CV == 1) RGB_DG3(T_, 1); \
+        else if (CV == 2) RGB_DG3(T_, 2); \
+        else if (CV == 4) RGB_DG3(T_, 4); \
+        else RGB_DG3(T_, 8);         \
+    } while (0)
+    if (dtype == GAN_F32) RGB_DG(float);
+    else RGB_DG(bf16);
+#undef RGB_DG
+#undef RGB_DG3
+    GAN_CHECK_LAUNCH("rgb_conv1x1_dgrad");
+    return GAN_OK;
+}
+
+extern "C" int64_t gan_rgb_conv1x1_wgrad_workspace(int Cin, int Cout) { return (int64_t)RGB_WG_BLOCKS * Cout * Cin; }
+
+extern "C" int gan_rgb_conv1x1_wgrad(const void* x, int x_dtype, int64_t sn, int64_t sc, int64_t sh, int64_t sw, const void* gy, int gy_dtype,
+                                     float* dw, float* workspace, int64_t workspace_floats, int N, int Cin, int H, int W, int Cout,
+                                     gan_stream_t stream) {
+    GAN_CHECK_ARG(N >= 0 && H > 0 && W > 0, "rgb_conv1x1_wgrad: bad shape");
+    GAN_CHECK_ARG(rgb_shape_ok(Cin, Cout), "rgb_conv1x1_wgrad: serves Cin <= 4 and Cout a multiple of 8 up to 64 (got %d, %d)", Cin, Cout);
+    GAN_CHECK_ARG((x_dtype == GAN_F32 || x_dtype == GAN_BF16) && (gy_dtype == GAN_F32 || gy_dtype == GAN_BF16), "rgb_conv1x1_wgrad: bad dtype");
+    GAN_CHECK_ARG(dw, "rgb_conv1x1_wgrad: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const int L = Cout * Cin;
+    if (N == 0) {
+        if (hipMemsetAsync(dw, 0, sizeof(float) * (size_t)L, st) != hipSuccess) {
+            gan_set_error("rgb_conv1x1_wgrad: memset failed");
+            return GAN_ERR_LAUNCH;
+        }
+        return GAN_OK;
+    }
+    GAN_CHECK_ARG(x && gy && ((uintptr_t)gy % 16) == 0, "rgb_conv1x1_wgrad: null or unaligned pointer");
+    const int64_t NP = (int64_t)N * H * W;
+    int64_t nb = ceil_div64(NP, (int64_t)RTPB * 8);  // >= 8 pixels per thread where the tensor allows
+    if (nb > RGB_WG_BLOCKS) nb = RGB_WG_BLOCKS;
+    if (nb < 1) nb = 1;
+    GAN_CHECK_ARG(workspace && workspace_floats >= nb * L, "rgb_conv1x1_wgrad: needs a workspace of gan_rgb_conv1x1_wgrad_workspace(...) floats");
+    const dim3 grid((unsigned)nb, (unsigned)(Cout / 8));
+    GAN_CHECK_ARG(NP < (1LL << 31), "rgb_conv1x1_wgrad: tensor too large");
+    const int lin = sh == (int64_t)W * sw;
+#define RGB_WG(TX, TG) \
+    hipLaunchKernelGGL((rgb_wgrad_k<TX, TG>), grid, dim3(RTPB), 0, st, (const TX*)x, sn, sc, sh, sw, (unsigned)W, lin, (const TG*)gy, workspace, (unsigned)NP, (unsigned)(H * W), Cin, Cout)
+    if (x_dtype == GAN_F32 && gy_dtype == GAN_F32) RGB_WG(float, float);
+    else if (x_dtype == GAN_F32) RGB_WG(float, bf16);
+    else if (gy_dtype == GAN_F32) RGB_WG(bf16, float);
+    else RGB_WG(bf16, bf16);
+#undef RGB_WG
+    GAN_CHECK_LAUNCH("rgb_conv1x1_wgrad");
+    hipLaunchKernelGGL(rgb_wgrad_fold_k, dim3((unsigned)L), dim3(64), 0, st, workspace, dw, (int)nb, L);
+    GAN_CHECK_LAUNCH("rgb_conv1x1_wgrad(fold)");
+    return GAN_OK;
+}

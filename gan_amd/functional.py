@@ -1125,6 +1125,122 @@ class MbstdBwdFn(Function):
         return gx2, (ggstat.to(ctx.gstat_dtype) if ggstat is not None else None), None
 
 
+# ---- the image boundary: 1x1 convolution from / to <= 4 channels (include/gan_amd.h: gan_rgb_conv1x1_*) ----------
+def _torch_dtype_code(dt: torch.dtype) -> int:
+    if dt == torch.float32:
+        return _lib.GAN_F32
+    if dt == torch.bfloat16:
+        return _lib.GAN_BF16
+    raise _lib.GanAmdError(f"gan_amd kernels take float32 or bfloat16, got {dt}")
+
+
+def rgb_conv_shape(x: Tensor, weight: Tensor) -> bool:
+    """Shapes the image-boundary kernels serve: a 1x1 convolution of a <= 4-channel 4-D tensor into 8..64 channels."""
+    cout, cin, kh, kw = weight.shape
+    return (x.dim() == 4 and kh == 1 and kw == 1 and cin == x.shape[1] and 1 <= cin <= 4 and 8 <= cout <= 64 and cout % 8 == 0
+            and x.dtype in (torch.float32, torch.bfloat16) and weight.dtype == torch.float32)
+
+
+def _raw_rgb_fwd(x: Tensor, weight: Tensor, bias: Optional[Tensor], slope: float, out_dtype: torch.dtype) -> Tensor:
+    require_gpu(x, weight, bias)
+    x = x.detach()
+    n, cin, h, w = x.shape
+    cout = weight.shape[0]
+    w32 = weight.detach().reshape(cout, cin).contiguous()
+    b32 = _f32(bias)
+    y = torch.empty((n, cout, h, w), dtype=out_dtype, device=x.device, memory_format=CL)
+    sn, sc, sh, sw = x.stride()
+    check(_run("rgb_conv1x1", 0, _nbytes(x, y),
+               lambda: _lib.load().gan_rgb_conv1x1_fwd(ptr(x), dtype_code(x), sn, sc, sh, sw, ptr(w32), ptr(b32), ptr(y), _torch_dtype_code(out_dtype),
+                                                       n, cin, h, w, cout, float(slope), stream_of(x)), (n, cin, h, w, cout)), "gan_rgb_conv1x1_fwd")
+    return y
+
+
+def _raw_rgb_dgrad(gy: Tensor, weight: Tensor) -> Tensor:
+    require_gpu(gy, weight)
+    gc = as_cl(gy.detach())
+    n, cout, h, w = gc.shape
+    cin = weight.shape[1]
+    w32 = weight.detach().float().reshape(cout, cin).contiguous()
+    gx = _empty_like_cl(gc, (n, cin, h, w))
+    check(_run("rgb_conv1x1_dgrad", 0, _nbytes(gc, gx),
+               lambda: _lib.load().gan_rgb_conv1x1_dgrad(ptr(gc), ptr(w32), ptr(gx), n * h * w, cin, cout, dtype_code(gc), stream_of(gc)), (n, cin, h, w, cout)),
+          "gan_rgb_conv1x1_dgrad")
+    return gx
+
+
+def _raw_rgb_wgrad(x: Tensor, gy: Tensor) -> Tensor:
+    require_gpu(x, gy)
+    lib = _lib.load()
+    x = x.detach()
+    gc = as_cl(gy.detach())
+    n, cin, h, w = x.shape
+    cout = gc.shape[1]
+    dw = torch.empty((cout, cin, 1, 1), dtype=torch.float32, device=x.device)
+    ws_floats = lib.gan_rgb_conv1x1_wgrad_workspace(cin, cout)
+    ws = torch.empty((ws_floats,), dtype=torch.float32, device=x.device)
+    sn, sc, sh, sw = x.stride()
+    check(_run("rgb_conv1x1_wgrad", 0, _nbytes(x, gc),
+               lambda: lib.gan_rgb_conv1x1_wgrad(ptr(x), dtype_code(x), sn, sc, sh, sw, ptr(gc), dtype_code(gc), ptr(dw), ptr(ws), ws_floats, n, cin, h, w,
+                                                 cout, stream_of(x)), (n, cin, h, w, cout)), "gan_rgb_conv1x1_wgrad")
+    return dw
+
+
+class RgbConvFn(Function):
+    """y = lrelu_slope(conv1x1(x, W) + b) for an image-like x (<= 4 channels, any strides, fp32 or bf16): the discriminator's
+    first layer (progressive_gan.py:61) without the padded copy.  RgbConvFn / RgbDgradFn / RgbWgradFn are closed under
+    differentiation like the Conv2d family (the map is bilinear; slope = 1 at this layer in every caller)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, slope, out_dtype):
+        y = _raw_rgb_fwd(x, weight, bias, slope, out_dtype)
+        ctx.save_for_backward(x, weight, bias, y if slope != 1.0 else None)
+        ctx.slope = slope
+        ctx.out_dtype = out_dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, bias, y = ctx.saved_tensors
+        gz = MaskMulFn.apply(gy, y, ctx.slope) if ctx.slope != 1.0 else gy
+        gx = RgbDgradFn.apply(gz, weight).to(x.dtype) if _need(ctx, 0) else None
+        gw = RgbWgradFn.apply(x, gz).to(weight.dtype) if _need(ctx, 1) else None
+        gb = ChanSumFn.apply(gz, False).reshape(bias.shape).to(bias.dtype) if bias is not None and _need(ctx, 2) else None
+        return gx, gw, gb, None, None
+
+
+class RgbDgradFn(Function):
+    """gx = gy . W over the output channels: the adjoint of RgbConvFn in x (channels-last, <= 4 channels, gy's dtype)."""
+
+    @staticmethod
+    def forward(ctx, gy, weight):
+        ctx.save_for_backward(gy, weight)
+        return _raw_rgb_dgrad(gy, weight)
+
+    @staticmethod
+    def backward(ctx, ggx):
+        gy, weight = ctx.saved_tensors
+        g_gy = RgbConvFn.apply(ggx, weight, None, 1.0, gy.dtype) if _need(ctx, 0) else None
+        g_w = RgbWgradFn.apply(ggx, gy).to(weight.dtype) if _need(ctx, 1) else None
+        return g_gy, g_w
+
+
+class RgbWgradFn(Function):
+    """dW = sum over samples and pixels of gy (x) x: the adjoint of RgbConvFn in W, fp32 (Cout, Cin, 1, 1)."""
+
+    @staticmethod
+    def forward(ctx, x, gy):
+        ctx.save_for_backward(x, gy)
+        return _raw_rgb_wgrad(x, gy)
+
+    @staticmethod
+    def backward(ctx, ggw):
+        x, gy = ctx.saved_tensors
+        g_x = RgbDgradFn.apply(gy, ggw.float()).to(x.dtype) if _need(ctx, 0) else None
+        g_gy = RgbConvFn.apply(x, ggw.float(), None, 1.0, gy.dtype) if _need(ctx, 1) else None
+        return g_x, g_gy
+
+
 def _raw_s2d(x: Tensor, pad: int, to_depth: bool, h: int, w: int, c: int) -> Tensor:
     """to_depth: x (N, C, H, W) -> (N, 4C, (H+2p)/2, (W+2p)/2); else x (N, 4C, Hb, Wb) -> (N, C, H, W) (h, w, c = the un-folded size)."""
     require_gpu(x)

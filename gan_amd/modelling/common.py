@@ -34,6 +34,12 @@ class Conv2d(nn.Conv2d):
 
     def forward(self, x: Tensor) -> Tensor:
         self._check()
+        if self.padding == (0, 0) and x.is_cuda and GF.rgb_conv_shape(x, self.weight):
+            # the image boundary (progressive_gan.py:61): reads the 3-channel tensor as it is -- fp32 or bf16, NCHW or
+            # channels-last -- instead of a cast pass, a 16-channel padded copy and a convolution over the copy
+            dt = GF.act_dtype(x)
+            if dt in (torch.float32, torch.bfloat16):
+                return GF.RgbConvFn.apply(x, self.weight, self.bias, 1.0, dt)
         x = to_act(x)
         if self.bias is not None and self.padding[0] == self.padding[1]:
             return GF.conv_bias_act(x, self.weight, self.bias, self.padding[0])  # bias on the accumulators

@@ -109,7 +109,9 @@ class ProgressiveGanDiscriminator(nn.Sequential):
         self.apply(init_weights)
 
     def forward(self, imgs: Tensor) -> Tensor:
-        x = to_act(imgs)
+        if imgs.dim() != 4:
+            raise GF._lib.GanAmdError(f"expected a 4-D (N, C, H, W) tensor, got shape {tuple(imgs.shape)}")
+        x = imgs  # the first convolution reads the image as it is (any strides, fp32 or bf16)
         *body, head = list(self)
         for m in body:
             x = m(x)

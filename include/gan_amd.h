@@ -223,6 +223,22 @@ int gan_mbstd_bwd2(const void* x, const float* gstat, const void* u, void* gx2, 
 int gan_mbstd_concat(const void* x, const float* stat, void* out, int N, int G, int64_t HW, int C, int dtype, gan_stream_t stream);
 int gan_mbstd_concat_adj(const void* g, void* gx, float* gstat, int N, int G, int64_t HW, int C, int dtype, gan_stream_t stream);
 
+/* ---- the image boundary: 1x1 convolution from / to <= 4 channels ---------------------------------------------------
+ * replaces nn.Conv2d(img_channels, base_dim, 1) of the discriminator (modelling/progressive_gan.py:61) and its two
+ * adjoints (autograd of it; R1 differentiates with respect to the image, losses.py:100-103), reading / writing the
+ * 3-channel tensor as it is (no 16-channel padded copy, no cast / layout pass in front):
+ *   fwd  : y[n][p][co] = lrelu_slope( sum_c x[n*sn + c*sc + h*sh + w*sw] * w[co][c] + bias[co] ),  y: [N][HW][Cout] (y_dtype)
+ *   dgrad: gx[n][p][c] = sum_co gy[n][p][co] * w[co][c],  gx: [N][HW][Cin] in gy's dtype
+ *   wgrad: dw[co][c]   = sum_{n,p} gy[n][p][co] * x[n, c, p]  (fp32; two deterministic stages through `workspace`,
+ *          at least gan_rgb_conv1x1_wgrad_workspace(Cin, Cout) floats, caller-owned)
+ * x: element strides, fp32 or bf16; w: fp32 [Cout][Cin] (the parameter itself); Cin <= 4, Cout % 8 == 0, Cout <= 64. */
+int gan_rgb_conv1x1_fwd(const void* x, int x_dtype, int64_t sn, int64_t sc, int64_t sh, int64_t sw, const float* w, const float* bias, void* y,
+                        int y_dtype, int N, int Cin, int H, int W, int Cout, float slope, gan_stream_t stream);
+int gan_rgb_conv1x1_dgrad(const void* gy, const float* w, void* gx, int64_t NP, int Cin, int Cout, int dtype, gan_stream_t stream);
+int64_t gan_rgb_conv1x1_wgrad_workspace(int Cin, int Cout);
+int gan_rgb_conv1x1_wgrad(const void* x, int x_dtype, int64_t sn, int64_t sc, int64_t sh, int64_t sw, const void* gy, int gy_dtype, float* dw,
+                          float* workspace, int64_t workspace_floats, int N, int Cin, int H, int W, int Cout, gan_stream_t stream);
+
 /* ---- stride-2 convolutions as stride-1 convolutions ------------------------------------------------------------
  * replaces the stride of nn.Conv2d(k, 2, p) / nn.ConvTranspose2d(k, 2, p) with even k in DCGAN (modelling/dcgan.py:21-29,
  * 50-60 through conv_norm_act, modelling/common.py:46-70): Conv_s2(x; W) = ValidConv_{k/2}(S2D_p(x); W') with

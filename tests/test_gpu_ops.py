@@ -819,3 +819,42 @@ def test_strided_conv_and_transpose_via_space_to_depth(dev, case, dtype):
         (g2,) = torch.autograd.grad(g[0].float().square().sum(), mod.weight)
         (g2r,) = torch.autograd.grad(gr[0].square().sum(), wr)
         assert rel_err(g2, g2r) < 3 * tol2, (case, transposed, rel_err(g2, g2r))
+
+
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("x_dtype,layout", [(torch.float32, "nchw"), (torch.bfloat16, "cl"), (torch.float32, "cl")])
+@pytest.mark.parametrize("out_dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", [(3, 3, 20, 28, 16), (2, 3, 64, 64, 64), (5, 1, 7, 9, 8), (2, 4, 33, 5, 32)])
+def test_rgb_conv1x1_family(dev, case, out_dtype, x_dtype, layout):
+    """gan_rgb_conv1x1_fwd / _dgrad / _wgrad (the discriminator's from-RGB layer, progressive_gan.py:61, read from the
+    image as it is) against F.conv2d in fp64: forward, all three gradients, and the second-order terms R1 needs."""
+    import gan_amd.functional as GF
+
+    n, cin, h, w, cout = case
+    tol, tol2 = (TOL32, TOL32_2) if out_dtype == torch.float32 else (TOLBF, 3 * TOLBF)
+    torch.manual_seed(1)
+    x = torch.randn(n, cin, h, w).to(x_dtype)
+    wgt = torch.randn(cout, cin, 1, 1) * 0.5
+    b = torch.randn(cout) * 0.3
+    xg = x.to(dev)
+    if layout == "cl":
+        xg = xg.contiguous(memory_format=torch.channels_last)
+    xg.requires_grad_(True)
+    wg, bg = wgt.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+    assert GF.rgb_conv_shape(xg, wg)
+    y = GF.RgbConvFn.apply(xg, wg, bg, 1.0, out_dtype)
+    xr, wr, br = x.double().requires_grad_(True), wgt.double().requires_grad_(True), b.double().requires_grad_(True)
+    ref = F.conv2d(xr, wr, br)
+    assert y.dtype == out_dtype and y.shape == ref.shape and rel_err(y, ref) < tol
+    coef = torch.randn(ref.shape)
+    g = torch.autograd.grad((y.float() * coef.to(dev)).sum(), [xg, wg, bg], create_graph=True)
+    gr = torch.autograd.grad((ref * coef.double()).sum(), [xr, wr, br], create_graph=True)
+    xtol = 3 * TOLBF if torch.bfloat16 in (x_dtype, out_dtype) else TOL32_2  # dL/dx comes back in x's dtype
+    for a, r_, nm in zip(g, gr, "xwb"):
+        assert rel_err(a, r_) < (xtol if nm == "x" else tol2), (nm, rel_err(a, r_))
+    tol2 = max(tol2, xtol)
+    # second order: (|dL/dx|^2 + |dL/dW|^2) differentiated with respect to W and x
+    g2 = torch.autograd.grad(g[0].float().square().sum() + g[1].square().sum(), [wg, xg])
+    g2r = torch.autograd.grad(gr[0].square().sum() + gr[1].square().sum(), [wr, xr])
+    for a, r_, nm in zip(g2, g2r, "wx"):
+        assert rel_err(a, r_) < 3 * tol2, (nm, rel_err(a, r_))
