@@ -26,6 +26,8 @@
 //   * One kernel per MODE: the generator's modulated convolution and the discriminator's convolutions
 //     use disjoint sets of fused stages; compiling them apart keeps the registers (occupancy) of each.
 #pragma once
+#include <stdlib.h>
+
 #include "common.h"
 
 enum ThinMode {
@@ -378,7 +380,15 @@ int pick_cin(const ThinArgs& a, int Cin, hipStream_t st) {
         case 8: return pick_cout<8, KS, 4>(a, st);
         case 16: return pick_cout<16, KS, 4>(a, st);
         case 32: return pick_cout<32, KS, 2>(a, st);
-        default: return pick_cout<64, KS, 2>(a, st);
+        default:
+            // 64 input channels: with 8-row tiles the halo + weights are 85 KB (Cout <= 32: one workgroup per CU); 4-row
+            // tiles bring that to 67 KB = two per CU (their load and MFMA phases overlap).  Cout = 64 stays at 8 rows: its
+            // 74 KB weight image alone pins it to one workgroup per CU either way.
+            // (not the pooled mode: a wave pools the row pair it owns)
+            if constexpr (KS == 3 && THIN_MODE != THIN_DP) {
+                if (a.Cout <= 32 && getenv("GAN_AMD_THIN64_RPW2") == nullptr) return pick_cout<64, KS, 1>(a, st);
+            }
+            return pick_cout<64, KS, 2>(a, st);
     }
 }
 
