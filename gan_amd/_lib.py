@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GAN_AMD_LIB") or os.path.join(_HERE, "libgan_amd.so")
 
 GAN_F32, GAN_BF16 = 0, 1
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 _SIGNATURES = {
     "gan_amd_version": (c_int, []),
@@ -30,9 +30,10 @@ _SIGNATURES = {
         [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_float, c_int, c_void_p],
     ),
     "gan_mask_scale": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int64, c_int, c_float, c_int, c_void_p]),
+    "gan_chan_dot_workspace": (c_int64, [c_int, c_int64, c_int, c_int]),
     "gan_chan_dot": (
         c_int,
-        [c_void_p, c_void_p, c_int, c_void_p, c_float, c_void_p, c_int64, c_int, c_int64, c_int, c_int, c_void_p],
+        [c_void_p, c_void_p, c_int, c_void_p, c_float, c_void_p, c_int64, c_int, c_int64, c_int, c_void_p, c_int64, c_int, c_void_p],
     ),
     "gan_conv2d_fwd": (
         c_int,

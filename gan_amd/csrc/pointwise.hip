@@ -324,14 +324,14 @@ extern "C" int gan_mask_scale(const void* g, const void* ymask, const float* a, 
 // channel reductions:  out[n*out_sn + c] += sum_hw A * m(ymask) * Bterm
 // Block = [R rows][CVT channel vectors]; each thread walks rows r, r+R, ...; partial sums are
 // folded across the lanes of a wave that hold the same channel vector with __shfl_xor (when
-// CVT is a power of two below 64), then across waves through LDS, then one fp32 atomic per
-// channel per block.
+// CVT is a power of two below 64), then across waves through LDS; every workgroup then STORES its
+// partial row to part[n][block][C] and chan_fold_k sums the rows in a fixed order: no atomics (deterministic), nothing to
+// zero, and the batch sum needs no separate reduction over the (N, C) partials.
 // =========================================================================================
 template <typename T, int V>
 __global__ void __launch_bounds__(TPB) chan_dot_k(const T* __restrict__ A, const T* __restrict__ B, int b_mode,
-                                                  const T* __restrict__ ymask, float slope, float* __restrict__ out,
-                                                  int64_t out_sn, int64_t HW, int C, int CVT, int R,
-                                                  int64_t rows_per_block) {
+                                                  const T* __restrict__ ymask, float slope, float* __restrict__ part,
+                                                  int64_t HW, int C, int CVT, int R, int64_t rows_per_block) {
     __shared__ float red[TPB * V];
     const int tid = threadIdx.x;
     const int tv = tid % CVT;
@@ -397,7 +397,7 @@ __global__ void __launch_bounds__(TPB) chan_dot_k(const T* __restrict__ A, const
             for (int e = 0; e < V; ++e) {
                 float s = 0.f;
                 for (int w = 0; w < TPB / 64; ++w) s += red[(w * CVT + tid) * V + e];
-                atomicAdd(out + n * out_sn + (int64_t)(blockIdx.z * CVT + tid) * V + e, s);
+                part[(n * gridDim.x + blockIdx.x) * C + (int64_t)(blockIdx.z * CVT + tid) * V + e] = s;
             }
         }
     } else {
@@ -409,43 +409,116 @@ __global__ void __launch_bounds__(TPB) chan_dot_k(const T* __restrict__ A, const
             for (int e = 0; e < V; ++e) {
                 float s = 0.f;
                 for (int r = 0; r < R; ++r) s += red[(r * CVT + tv) * V + e];
-                atomicAdd(out + n * out_sn + c + e, s);
+                part[(n * gridDim.x + blockIdx.x) * C + c + e] = s;
             }
         }
     }
 }
 
+// out[g][c] = sum_r part[g * rows + r][c]: G groups of `rows` partial rows (per-sample sums: G = N, rows = blocks per
+// sample; batch sums: G = 1, rows = N * blocks).  A workgroup = RG row lanes x CW channel vectors of V floats (RG a power
+// of two sized to the row count by the launcher); row lanes are folded by a tree through LDS, in a fixed order.
+template <int V>
+__global__ void __launch_bounds__(TPB) chan_fold_k(const float* __restrict__ part, float* __restrict__ out, int rows, int C, int CW, int RG) {
+    __shared__ float red[TPB * V];
+    const int tc = threadIdx.x % CW, tr = threadIdx.x / CW;
+    const int c = (blockIdx.x * CW + tc) * V;
+    const int64_t g = blockIdx.y;
+    float acc[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) acc[e] = 0.f;
+    if (c < C && tr < RG) {  // (CW is capped by the channel count: lanes past RG * CW idle)
+        const float* __restrict__ src = part + g * rows * (int64_t)C + c;
+#pragma unroll 4
+        for (int r = tr; r < rows; r += RG) {
+            float t[V];
+            load_f<float, V>(src + (int64_t)r * C, t);
+#pragma unroll
+            for (int e = 0; e < V; ++e) acc[e] += t[e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < V; ++e) red[threadIdx.x * V + e] = acc[e];
+    __syncthreads();
+    for (int s = RG >> 1; s > 0; s >>= 1) {
+        if (tr < s) {
+#pragma unroll
+            for (int e = 0; e < V; ++e) red[threadIdx.x * V + e] += red[(threadIdx.x + s * CW) * V + e];
+        }
+        __syncthreads();
+    }
+    if (tr == 0 && c < C) {
+#pragma unroll
+        for (int e = 0; e < V; ++e) out[g * C + c + e] = red[threadIdx.x * V + e];
+    }
+}
+
+struct ChanDotPlan {
+    int V, cv, CVT, R, zchunks;
+    int64_t bps, rpb;
+};
+
 template <typename T>
-static int chan_dot_launch(const void* A, const void* B, int b_mode, const void* ymask, float slope, float* out,
-                           int64_t out_sn, int N, int64_t HW, int C, hipStream_t st) {
+static ChanDotPlan chan_dot_plan(int N, int64_t HW, int C) {
+    ChanDotPlan pl;
     constexpr int VV = VecOf<T>::V;
-    const bool vec = (C % VV) == 0;
-    const int V = vec ? VV : 1;
-    const int cv = C / V;
-    const int CVT = cv < TPB ? cv : TPB;
-    const int R = TPB / CVT;
-    const int zchunks = (cv + CVT - 1) / CVT;
-    int64_t bps = ceil_div64(HW, (int64_t)R * 4);  // >= 4 rows per thread when possible
-    const int64_t cap = 4096 / ((int64_t)N * zchunks) > 0 ? 4096 / ((int64_t)N * zchunks) : 1;
+    pl.V = (C % VV) == 0 ? VV : 1;
+    pl.cv = C / pl.V;
+    pl.CVT = pl.cv < TPB ? pl.cv : TPB;
+    pl.R = TPB / pl.CVT;
+    pl.zchunks = (pl.cv + pl.CVT - 1) / pl.CVT;
+    int64_t bps = ceil_div64(HW, (int64_t)pl.R * 4);  // >= 4 rows per thread when possible
+    const int64_t cap = 4096 / ((int64_t)N * pl.zchunks) > 0 ? 4096 / ((int64_t)N * pl.zchunks) : 1;
     if (bps > cap) bps = cap;
     if (bps < 1) bps = 1;
     int64_t rpb = ceil_div64(HW, bps);
-    rpb = ceil_div64(rpb, R) * R;
-    bps = ceil_div64(HW, rpb);
-    GAN_CHECK_ARG(N <= 65535 && zchunks <= 65535, "chan_dot: N or C too large for the grid");
-    dim3 grid((unsigned)bps, (unsigned)N, (unsigned)zchunks);
-    if (vec)
+    rpb = ceil_div64(rpb, pl.R) * pl.R;
+    pl.rpb = rpb;
+    pl.bps = ceil_div64(HW, rpb);
+    return pl;
+}
+
+template <typename T>
+static int chan_dot_launch(const void* A, const void* B, int b_mode, const void* ymask, float slope, float* out,
+                           int64_t out_sn, int N, int64_t HW, int C, float* ws, hipStream_t st) {
+    constexpr int VV = VecOf<T>::V;
+    const ChanDotPlan pl = chan_dot_plan<T>(N, HW, C);
+    GAN_CHECK_ARG(N <= 65535 && pl.zchunks <= 65535, "chan_dot: N or C too large for the grid");
+    const bool direct = out_sn != 0 && pl.bps == 1;  // one workgroup per (sample, channel chunk): its row IS the result
+    float* part = direct ? out : ws;
+    dim3 grid((unsigned)pl.bps, (unsigned)N, (unsigned)pl.zchunks);
+    if (pl.V == VV)
         hipLaunchKernelGGL((chan_dot_k<T, VV>), grid, dim3(TPB), 0, st, (const T*)A, (const T*)B, b_mode,
-                           (const T*)ymask, slope, out, out_sn, HW, C, CVT, R, rpb);
+                           (const T*)ymask, slope, part, HW, C, pl.CVT, pl.R, pl.rpb);
     else
         hipLaunchKernelGGL((chan_dot_k<T, 1>), grid, dim3(TPB), 0, st, (const T*)A, (const T*)B, b_mode,
-                           (const T*)ymask, slope, out, out_sn, HW, C, CVT, R, rpb);
+                           (const T*)ymask, slope, part, HW, C, pl.CVT, pl.R, pl.rpb);
     GAN_CHECK_LAUNCH("chan_dot");
+    if (direct) return GAN_OK;
+    const int rows = (int)(out_sn ? pl.bps : (int64_t)N * pl.bps);
+    const int FV = (C % 4) == 0 ? 4 : 1, cvf = C / FV;
+    int RG = 1;  // row lanes: ~4 rows per lane, at most the whole workgroup
+    while (RG < TPB && RG * 4 < rows) RG <<= 1;
+    int CW = TPB / RG;
+    if (CW > cvf) CW = cvf;
+    const dim3 fgrid((unsigned)((cvf + CW - 1) / CW), (unsigned)(out_sn ? N : 1));
+    if (FV == 4)
+        hipLaunchKernelGGL(chan_fold_k<4>, fgrid, dim3(TPB), 0, st, ws, out, rows, C, CW, RG);
+    else
+        hipLaunchKernelGGL(chan_fold_k<1>, fgrid, dim3(TPB), 0, st, ws, out, rows, C, CW, RG);
+    GAN_CHECK_LAUNCH("chan_dot(fold)");
     return GAN_OK;
 }
 
+extern "C" int64_t gan_chan_dot_workspace(int N, int64_t HW, int C, int dtype) {
+    if (N <= 0 || HW <= 0 || C <= 0) return 0;
+    const ChanDotPlan pl = dtype == GAN_F32 ? chan_dot_plan<float>(N, HW, C) : chan_dot_plan<bf16>(N, HW, C);
+    return (int64_t)N * pl.bps * C;
+}
+
 extern "C" int gan_chan_dot(const void* A, const void* B, int b_mode, const void* ymask, float slope, float* out,
-                            int64_t out_stride_n, int N, int64_t HW, int C, int dtype, gan_stream_t stream) {
+                            int64_t out_stride_n, int N, int64_t HW, int C, float* workspace, int64_t workspace_floats, int dtype,
+                            gan_stream_t stream) {
     GAN_CHECK_ARG(N >= 0 && HW >= 0 && C > 0, "chan_dot: bad shape");
     GAN_CHECK_ARG((A || N == 0 || HW == 0) && (out || (out_stride_n && N == 0)), "chan_dot: null pointer");
     GAN_CHECK_ARG(b_mode >= 0 && b_mode <= 2 && ((b_mode == 0) == (B == nullptr)), "chan_dot: b_mode %d vs B", b_mode);
@@ -454,13 +527,17 @@ extern "C" int gan_chan_dot(const void* A, const void* B, int b_mode, const void
     hipStream_t st = (hipStream_t)stream;
     const size_t bytes = sizeof(float) * (size_t)(out_stride_n ? (int64_t)N * C : C);
     if (bytes == 0) return GAN_OK;
-    if (hipMemsetAsync(out, 0, bytes, st) != hipSuccess) {
-        gan_set_error("chan_dot: memset failed");
-        return GAN_ERR_LAUNCH;
+    if (N == 0 || HW == 0) {
+        if (hipMemsetAsync(out, 0, bytes, st) != hipSuccess) {
+            gan_set_error("chan_dot: memset failed");
+            return GAN_ERR_LAUNCH;
+        }
+        return GAN_OK;
     }
-    if (N == 0 || HW == 0) return GAN_OK;
-    if (dtype == GAN_F32) return chan_dot_launch<float>(A, B, b_mode, ymask, slope, out, out_stride_n, N, HW, C, st);
-    return chan_dot_launch<bf16>(A, B, b_mode, ymask, slope, out, out_stride_n, N, HW, C, st);
+    GAN_CHECK_ARG(workspace != nullptr && workspace_floats >= gan_chan_dot_workspace(N, HW, C, dtype),
+                  "chan_dot: needs a workspace of gan_chan_dot_workspace(...) = %lld floats", (long long)gan_chan_dot_workspace(N, HW, C, dtype));
+    if (dtype == GAN_F32) return chan_dot_launch<float>(A, B, b_mode, ymask, slope, out, out_stride_n, N, HW, C, workspace, st);
+    return chan_dot_launch<bf16>(A, B, b_mode, ymask, slope, out, out_stride_n, N, HW, C, workspace, st);
 }
 
 // =========================================================================================

@@ -219,20 +219,20 @@ def raw_chan_dot(A: Tensor, B: Optional[Tensor], b_mode: int, ymask: Optional[Te
         B = None
     if ymask is not None:
         ymask = as_cl(ymask.detach().to(A.dtype))
-    # Always reduce per sample in the kernel: N x fewer workgroups add into one address (a batch-wide sum
-    # straight from the kernel is bound by fp32-atomic contention, 0.08-0.17 TB/s measured); the (N, C)
-    # partials are folded over N by one tiny reduction.  (Adding straight into (C,) was tried for small tensors:
-    # 59 us against 13 us at N = 256 and 25 us against 14 us at N = 32 for 512 channels on 4x4 .. 8x8.)
-    out = torch.empty((n, c), dtype=torch.float32, device=A.device)
+    # two deterministic stages in the library (partial rows -> fold): the batch sum comes out of the same call
+    out = torch.empty((n, c) if per_sample else (c,), dtype=torch.float32, device=A.device)
+    ws_floats = lib.gan_chan_dot_workspace(n, h * w, c, dtype_code(A))
+    ws = torch.empty((max(ws_floats, 1),), dtype=torch.float32, device=A.device)
     check(
         _run(
             "chan_dot", 0, _nbytes(A, B, ymask),
-            lambda: lib.gan_chan_dot(ptr(A), ptr(B), b_mode, ptr(ymask), float(slope), ptr(out), c, n, h * w, c, dtype_code(A), stream_of(A)),
+            lambda: lib.gan_chan_dot(ptr(A), ptr(B), b_mode, ptr(ymask), float(slope), ptr(out), c if per_sample else 0, n, h * w, c, ptr(ws), ws_floats,
+                                     dtype_code(A), stream_of(A)),
             (n, c, h, w, b_mode, int(ymask is not None), int(per_sample)),
         ),
         "gan_chan_dot",
     )
-    return out if per_sample else out.sum(0)
+    return out
 
 
 def raw_modconv_bwd_pre(gy: Tensor, y: Optional[Tensor], noise: Optional[Tensor], dinv: Optional[Tensor], slope: float):

@@ -73,13 +73,17 @@ int gan_affine_act_fwd(const void* x, const float* a, int64_t a_stride_n, const 
 int gan_mask_scale(const void* g, const void* ymask, const float* a, int64_t a_stride_n, void* out, int N,
                    int64_t HW, int C, float slope, int dtype, gan_stream_t stream);
 
-/* Channel reductions for bias / noise-scale / style / demodulation / D-block `scale` gradients
- * (wavefront shuffle + LDS reduction, fp32 atomics across workgroups; `out` is zeroed here):
+/* Channel reductions for bias / noise-scale / style / demodulation / D-block `scale` gradients:
  * out[n*out_stride_n + c] = sum_hw A[n,hw,c] * m(ymask[n,hw,c]) * Bterm,
  *   Bterm = B[n,hw,c] (b_mode 1), B[n,hw] broadcast over c (b_mode 2), or 1 (b_mode 0).
- * out_stride_n = C gives per-sample sums [N][C]; out_stride_n = 0 gives batch sums [C]. */
+ * out_stride_n = C gives per-sample sums [N][C]; out_stride_n = 0 gives batch sums [C].
+ * Two deterministic stages (wavefront shuffle + LDS reduction per workgroup, partial rows stored to `workspace`, a fold
+ * kernel that sums them in a fixed order): no atomics, `out` need not be zeroed, every element of it is written.
+ * workspace: at least gan_chan_dot_workspace(N, HW, C, dtype) floats, caller-owned (the library never allocates). */
+int64_t gan_chan_dot_workspace(int N, int64_t HW, int C, int dtype);
 int gan_chan_dot(const void* A, const void* B, int b_mode, const void* ymask, float slope, float* out,
-                 int64_t out_stride_n, int N, int64_t HW, int C, int dtype, gan_stream_t stream);
+                 int64_t out_stride_n, int N, int64_t HW, int C, float* workspace, int64_t workspace_floats, int dtype,
+                 gan_stream_t stream);
 
 /* Fused passes of the modulated convolution's backward (autograd of ModulatedConv2d.forward,
  * modelling/stylegan2.py:29-36; they replace three gan_chan_dot calls + one gan_mask_scale, and one of each):
