@@ -146,6 +146,12 @@ int gan_conv2d_fwd_wide(const void* x, const void* wt, void* y, const float* out
                         int Ho, int Wo, int Cout, int kh, int kw, int py, int px, int Kpad, const ConvFuse& fu,
                         hipStream_t st);
 
+// conv_wide_halo.hip: the 3x3 case of the above with the input halo resident in LDS across the nine taps.
+int gan_conv2d_fwd_wide_halo(const void* x, const void* wt, void* y, const float* out_scale, const float* bias,
+                             const void* noise, const float* noise_scale, float slope, int N, int H, int W, int Cin,
+                             int up2, int Ho, int Wo, int Cout, int kh, int kw, int py, int px, int Kpad,
+                             const ConvFuse& fu, hipStream_t st);
+
 // Fused stages of the weight gradient (include/gan_amd.h): leaky-ReLU of x as it is staged, gy given at half
 // resolution (nearest-neighbour upsampled in the gather: the adjoint of 2x2 pooling, with gain 0.25), scalar gain.
 struct WgradFuse {

@@ -280,6 +280,10 @@ int gan_conv2d_fwd_wide(const void* x, const void* wt, void* y, const float* out
                         int Ho, int Wo, int Cout, int kh, int kw, int py, int px, int Kpad, const ConvFuse& fu,
                         hipStream_t st) {
     if (Cin % 64 != 0 || Kpad != kh * kw * Cin || (Cout & 3) || fu.in_slope != 1.f) return 0;
+    // 3x3 layers on grids that fill the chip: the resident-halo kernel (conv_wide_halo.hip)
+    const int halo = gan_conv2d_fwd_wide_halo(x, wt, y, out_scale, bias, noise, noise_scale, slope, N, H, W, Cin, up2, Ho, Wo, Cout, kh, kw, py,
+                                              px, Kpad, fu, st);
+    if (halo != 0) return halo;
     const int64_t M = (int64_t)N * Ho * Wo;
     const int64_t xb = (int64_t)N * H * W * Cin * 2, wb = (int64_t)Cout * Kpad * 2;
     const int64_t yb = (fu.pool ? M / 4 : M) * Cout * 2;

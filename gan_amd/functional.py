@@ -20,7 +20,7 @@ these primitives.
 from __future__ import annotations
 
 import weakref
-from typing import Optional, Tuple
+from typing import Dict, Optional, Tuple
 
 import torch
 import torch.nn.functional as F
@@ -434,6 +434,31 @@ def _wide_kernel_shape(x: Tensor, cin_p: int, cout: int, ho: int, wo: int, kh: i
     return not _thin_kernel_shape(x, cin_p, cout, ho, wo, kh, kw, py, px)
 
 
+_CUS: Dict[int, int] = {}
+
+
+def _halo_kernel_shape(x: Tensor, cout: int, ho: int, wo: int, kh: int, kw: int, py: int, px: int, up2: bool) -> bool:
+    """Mirror of conv_wide_halo.hip's eligibility among the wide shapes: 3x3 same-size convolutions on maps of 8 / 16k
+    pixels a side whose tiles fill the chip (profile family only: the library decides by itself)."""
+    import os
+
+    mode = int(os.environ.get("GAN_AMD_HALO", "1"))
+    n, _, h, w = x.shape
+    if mode == 0 or kh != 3 or kw != 3 or py != 1 or px != 1 or cout % 8 or ho != (2 * h if up2 else h) or wo != (2 * w if up2 else w):
+        return False
+    t16 = ho % 16 == 0 and wo % 16 == 0
+    if not t16 and (ho % 8 or wo % 8):
+        return False
+    bn = 128 if cout > 64 else 64
+    waves = 4 if (t16 and bn == 128) else 8
+    tiles = -(-n // (1 if t16 else 4)) * (wo // (16 if t16 else 8)) * (ho // (2 * waves if t16 else 8))
+    dev = x.device.index or 0
+    if dev not in _CUS:
+        _CUS[dev] = torch.cuda.get_device_properties(dev).multi_processor_count
+    slots = _CUS[dev] * (2 if waves == 4 else 1)
+    return mode == 2 or tiles * -(-cout // bn) >= slots - slots // 8
+
+
 def _thin_kernel_shape(x: Tensor, cin_p: int, cout: int, ho: int, wo: int, kh: int, kw: int, py: int, px: int) -> bool:
     """Shapes conv_thin.hip serves (HBM-bound direct convolution); used to pick the profile family too."""
     return (x.dtype == torch.bfloat16 and kh == kw and kh in (1, 3) and py == px == (kh - 1) // 2
@@ -523,6 +548,8 @@ def raw_conv2d(
         # (mirror of the launch selection in conv_wide.hip)
         big = cout > 64 and ((n * ho * wo + 127) // 128) * ((cout + 127) // 128) >= 256
         family = "conv2d_fwd_wide128" if big else "conv2d_fwd_wide64"
+        if _halo_kernel_shape(x, cout, ho, wo, kh, kw, py, px, up2):
+            family = "conv2d_fwd_wide_halo"  # conv_wide_halo_k<BN, waves, up2>: the halo stays in LDS across the taps
     else:
         family = "conv2d_fwd"
     check(

@@ -547,6 +547,65 @@ def test_conv2d_wide_kernel(dev, case):
     assert rel_err(got2, ref2) < 4e-3, rel_err(got2, ref2)
 
 
+HALO_CASES = [
+    # N, Cin, H, W, Cout, k, up2, pool   (3x3, Cin % 64 == 0, maps of 8 / 16k pixels a side: conv_wide_halo.hip)
+    (3, 128, 32, 32, 128, 3, False, False),  # 16 x 16 tiles, two channel blocks
+    (2, 128, 32, 32, 256, 3, False, True),  # pooling: vertical pair in registers, horizontal by DPP
+    (7, 512, 8, 8, 512, 3, False, False),  # 4 images per tile, N % 4 != 0
+    (6, 256, 8, 8, 128, 3, False, True),
+    (5, 256, 4, 4, 128, 3, True, False),  # nearest-2x, 8 x 8 output from a 6 x 6 source halo
+    (3, 256, 8, 8, 128, 3, True, False),  # nearest-2x, 16 x 16 output
+    (2, 128, 32, 32, 64, 3, True, False),  # Cout = 64: BN = 64 tile
+    (2, 64, 64, 64, 64, 3, False, True),
+    (2, 192, 16, 48, 72, 3, False, False),  # Cout tail, non-square map
+    (5, 64, 8, 16, 136, 3, False, False),  # 8 x 8 tiling of a non-square map
+]
+
+
+@pytest.mark.parametrize("case", HALO_CASES)
+def test_conv2d_wide_halo_kernel(dev, case, monkeypatch):
+    """The resident-halo kernel on every tiling / fused stage, forced also on grids it would leave to conv_wide.hip
+    (GAN_AMD_HALO = 2), and bit-compared with that kernel (GAN_AMD_HALO = 0): both accumulate a pixel's taps in the
+    same order (tap-major inside a channel block is the only difference), so they agree to fp32 rounding."""
+    import gan_amd.functional as GF
+
+    n, cin, h, w, cout, k, up2, pool = case
+    torch.manual_seed(37)
+    x = torch.randn(n, cin, h, w).bfloat16().to(dev)
+    wgt = (torch.randn(cout, cin, k, k) / (cin * k * k) ** 0.5).bfloat16().float().to(dev)
+    d = (torch.rand(n, cout) + 0.5).to(dev)
+    b = torch.randn(cout).to(dev)
+    ns = torch.randn(cout).to(dev)
+    ho, wo = (2 * h, 2 * w) if up2 else (h, w)
+    hy, wy = (ho // 2, wo // 2) if pool else (ho, wo)
+    noise = torch.randn(n, 1, hy, wy).bfloat16().to(dev)
+    aux = torch.randn(n, cout, hy, wy).bfloat16().to(dev)
+    res = torch.randn(n, cout, hy, wy).bfloat16().to(dev).contiguous(memory_format=torch.channels_last)
+
+    def run():
+        g = GF.raw_conv2d(x, wgt, 1, 1, up2=up2, out_scale=d, bias=b, noise=noise, noise_scale=ns, slope=0.2, pool=pool)
+        dd = GF.raw_conv2d(x, wgt, 1, 1, up2=up2, bias=b, pool=pool, aux=aux, aux_slope=0.2, gain=0.25, resid=res)
+        return g, dd
+
+    monkeypatch.setenv("GAN_AMD_HALO", "2")
+    got = run()
+    monkeypatch.setenv("GAN_AMD_HALO", "0")
+    ref = run()
+    xl = x.double().cpu()
+    if up2:
+        xl = xl.repeat_interleave(2, 2).repeat_interleave(2, 3)
+    z = F.conv2d(xl, wgt.double().cpu(), padding=1)
+    if pool:
+        z = F.avg_pool2d(z, 2)
+    o1 = F.leaky_relu(z * d.double().cpu().view(n, cout, 1, 1) + b.double().cpu().view(1, -1, 1, 1)
+                      + noise.double().cpu() * ns.double().cpu().view(1, -1, 1, 1), 0.2)
+    o2 = (z * 0.25 + b.double().cpu().view(1, -1, 1, 1)) * torch.where(aux.double().cpu() > 0, 1.0, 0.2) + res.double().cpu()
+    for g, r, o in zip(got, ref, (o1, o2)):
+        assert g.shape == o.shape and g.dtype == torch.bfloat16
+        assert rel_err(g, o) < 4e-3, rel_err(g, o)
+        assert rel_err(g, r.float()) < 2e-3  # two bf16 roundings of nearly equal fp32 sums
+
+
 @pytest.mark.parametrize("shape", [(4, 16, 24, 3), (7, 512, 512, 3), (256, 33, 5, 1), (3, 64, 128, 3)])
 def test_demod_kernels(dev, shape):
     """gan_demod_fwd / gan_demod_bwd against F.normalize's norm (stylegan2.py:33) differentiated by torch in fp64."""
