@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GAN_AMD_LIB") or os.path.join(_HERE, "libgan_amd.so")
 
 GAN_F32, GAN_BF16 = 0, 1
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 _SIGNATURES = {
     "gan_amd_version": (c_int, []),
@@ -33,14 +33,14 @@ _SIGNATURES = {
     "gan_chan_dot_workspace": (c_int64, [c_int, c_int64, c_int, c_int]),
     "gan_chan_dot": (
         c_int,
-        [c_void_p, c_void_p, c_int, c_void_p, c_float, c_void_p, c_int64, c_int, c_int64, c_int, c_void_p, c_int64, c_int, c_void_p],
+        [c_void_p, c_void_p, c_int, c_void_p, c_float, c_void_p, c_int64, c_int, c_int64, c_int, c_void_p, c_int64, c_int, c_int, c_void_p],
     ),
     "gan_conv2d_fwd": (
         c_int,
         [c_void_p] * 8 + [c_float] + [c_int] * 13 + [c_float, c_int, c_void_p, c_float, c_float, c_void_p] + [c_int, c_void_p],
     ),
     "gan_conv2d_wgrad_workspace": (c_int64, [c_int] * 13),
-    "gan_conv2d_wgrad": (c_int, [c_void_p] * 3 + [c_int, c_int, c_void_p] + [c_int] * 12 + [c_void_p, c_int64, c_float, c_int, c_float, c_int, c_void_p]),
+    "gan_conv2d_wgrad": (c_int, [c_void_p] * 3 + [c_int, c_int, c_void_p] + [c_int] * 12 + [c_void_p, c_int64, c_float, c_int, c_float, c_int, c_int, c_void_p]),
     "gan_amd_init": (c_int, []),
     "gan_conv2d_wgrad_static_max_floats": (c_int64, []),
     "gan_conv2d_wgrad_static": (c_int, [c_void_p] * 3 + [c_int, c_int, c_void_p] + [c_int] * 12 + [c_float, c_int, c_float, c_int, c_void_p]),

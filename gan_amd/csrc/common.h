@@ -165,6 +165,7 @@ struct WgradFuse {
 struct DwOut {
     float* out;
     int cout, cin;
+    int accumulate;  // 1: dw += result (the caller's gradient buffer), 0: dw = result
 };
 
 // conv_thin_wgrad.hip: weight gradient for thin layers (bf16, needs the workspace it reports through `need`).

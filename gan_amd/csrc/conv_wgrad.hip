@@ -241,7 +241,7 @@ extern "C" int64_t gan_conv2d_wgrad_workspace(int N, int H, int W, int Cin, int 
     const int64_t L = (int64_t)kh * kw * Cout * Cin;  // every path folds at least one padded slice into dw
     if (dtype != GAN_BF16) return L;
     int64_t need = 0;
-    gan_conv2d_wgrad_thin(nullptr, nullptr, DwOut{nullptr, 0, 0}, nullptr, N, H, W, Cin, up2, Ho, Wo, Cout, kh, kw, py, px, nullptr, 0,
+    gan_conv2d_wgrad_thin(nullptr, nullptr, DwOut{nullptr, 0, 0, 0}, nullptr, N, H, W, Cin, up2, Ho, Wo, Cout, kh, kw, py, px, nullptr, 0,
                           &need, WgradFuse{1.f, 0, 1.f}, nullptr);
     if (need == 0) need = gan_wgrad_tiled_workspace(N, Ho, Wo, Cin, Cout, kh, kw, py, px);
     return need > L ? need : L;
@@ -249,9 +249,10 @@ extern "C" int64_t gan_conv2d_wgrad_workspace(int N, int H, int W, int Cin, int 
 
 static int wgrad_impl(const void* x, const void* gy, float* dw, int Cout_out, int Cin_out, const float* in_scale, int N,
                       int H, int W, int Cin, int up2, int Ho, int Wo, int Cout, int kh, int kw, int py, int px,
-                      float* workspace, int64_t workspace_floats, float x_slope, int gy_up2, float gain,
+                      float* workspace, int64_t workspace_floats, float x_slope, int gy_up2, float gain, int accumulate,
                       int dtype, gan_stream_t stream) {
     GAN_CHECK_ARG(dw && (N == 0 || (x && gy)), "conv2d_wgrad: null pointer");
+    GAN_CHECK_ARG(accumulate == 0 || accumulate == 1, "conv2d_wgrad: accumulate must be 0 or 1");
     GAN_CHECK_ARG(dtype == GAN_F32 || dtype == GAN_BF16, "conv2d_wgrad: bad dtype %d", dtype);
     GAN_CHECK_ARG(N >= 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Ho > 0 && Wo > 0, "conv2d_wgrad: bad shape");
     GAN_CHECK_ARG(Cin % 16 == 0 && Cout % 16 == 0, "conv2d_wgrad: Cin=%d and Cout=%d must be multiples of 16 (pad)",
@@ -267,10 +268,11 @@ static int wgrad_impl(const void* x, const void* gy, float* dw, int Cout_out, in
     GAN_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)gy % 16) == 0, "conv2d_wgrad: x and gy must be 16-byte aligned");
     GAN_CHECK_ARG(gy_up2 == 0 || (gy_up2 == 1 && Ho % 2 == 0 && Wo % 2 == 0), "conv2d_wgrad: gy_up2 needs an even %dx%d output", Ho, Wo);
     const WgradFuse fu{x_slope, gy_up2, gain};
-    const DwOut dwo{dw, Cout_out, Cin_out};
+    const DwOut dwo{dw, Cout_out, Cin_out, accumulate};
     hipStream_t st = (hipStream_t)stream;
     const int64_t L = (int64_t)kh * kw * Cout * Cin;
     if (N == 0) {
+        if (accumulate) return GAN_OK;
         if (hipMemsetAsync(dw, 0, sizeof(float) * (size_t)kh * kw * Cout_out * Cin_out, st) != hipSuccess) {
             gan_set_error("conv2d_wgrad: memset failed");
             return GAN_ERR_LAUNCH;
@@ -309,10 +311,10 @@ static int wgrad_impl(const void* x, const void* gy, float* dw, int Cout_out, in
 
 extern "C" int gan_conv2d_wgrad(const void* x, const void* gy, float* dw, int Cout_out, int Cin_out, const float* in_scale, int N,
                                 int H, int W, int Cin, int up2, int Ho, int Wo, int Cout, int kh, int kw, int py, int px,
-                                float* workspace, int64_t workspace_floats, float x_slope, int gy_up2, float gain,
+                                float* workspace, int64_t workspace_floats, float x_slope, int gy_up2, float gain, int accumulate,
                                 int dtype, gan_stream_t stream) {
     return wgrad_impl(x, gy, dw, Cout_out, Cin_out, in_scale, N, H, W, Cin, up2, Ho, Wo, Cout, kh, kw, py, px, workspace,
-                      workspace_floats, x_slope, gy_up2, gain, dtype, stream);
+                      workspace_floats, x_slope, gy_up2, gain, accumulate, dtype, stream);
 }
 
 // ---- the entry point that allocates nothing (include/gan_amd.h: gan_conv2d_wgrad_static) ------------------------
@@ -367,5 +369,5 @@ extern "C" int gan_conv2d_wgrad_static(const void* x, const void* gy, float* dw,
     // Every slice the kernels read they have written in this call (plain stores), and the atomics path clears its one
     // slice with hipMemsetAsync on `stream` first: nothing of the previous call's contents is read.
     return wgrad_impl(x, gy, dw, Cout_out, Cin_out, in_scale, N, H, W, Cin, up2, Ho, Wo, Cout, kh, kw, py, px, ws,
-                      (int64_t)GAN_WGRAD_STATIC_MAX_FLOATS, x_slope, gy_up2, gain, dtype, stream);
+                      (int64_t)GAN_WGRAD_STATIC_MAX_FLOATS, x_slope, gy_up2, gain, 0, dtype, stream);
 }

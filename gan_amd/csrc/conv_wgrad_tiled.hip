@@ -276,12 +276,12 @@ __global__ void __launch_bounds__(TW_THREADS) conv_wgrad_tiled_k(const TWArgs p)
     }
 }
 
-// dw[co][ci][tap] = gain * sum_s ws[s][tap][co][ci]: folds the split-K slices and writes the parameter's own
+// dw[co][ci][tap] (+)= gain * sum_s ws[s][tap][co][ci]: folds the split-K slices and writes the parameter's own
 // layout (cout x cin x taps, channel padding dropped), so the caller needs neither a zeroed target nor a
 // permute / slice copy afterwards.  A block owns 64 quads of consecutive ci; its SG waves split the slices.
 template <int SG>
 __global__ void __launch_bounds__(64 * SG) finalize_dw_k(const float* __restrict__ ws, float* __restrict__ out, int64_t L, int S,
-                                                         int taps, int Cout, int Cin, int cout_o, int cin_o, float gain) {
+                                                         int taps, int Cout, int Cin, int cout_o, int cin_o, float gain, int accum) {
     __shared__ float4 part[SG * 64];
     const int lane = threadIdx.x & 63, sg = threadIdx.x >> 6;
     const int64_t e4 = (int64_t)blockIdx.x * 64 + lane;
@@ -317,7 +317,7 @@ __global__ void __launch_bounds__(64 * SG) finalize_dw_k(const float* __restrict
     float* __restrict__ o = out + ((int64_t)co * cin_o + ci) * taps + tap;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-        if (ci + j < cin_o) o[(int64_t)j * taps] = r[j];
+        if (ci + j < cin_o) o[(int64_t)j * taps] = accum ? o[(int64_t)j * taps] + r[j] : r[j];
 }
 
 struct TiledPlan {
@@ -429,11 +429,11 @@ int gan_finalize_dw(const float* ws, int S, int taps, int Cout, int Cin, const D
     }
     const unsigned blocks = (unsigned)ceil_div64(ceil_div64(L, 4), 64);
     if (S <= 8)
-        hipLaunchKernelGGL(finalize_dw_k<1>, dim3(blocks), dim3(64), 0, st, ws, dwo.out, L, S, taps, Cout, Cin, dwo.cout, dwo.cin, gain);
+        hipLaunchKernelGGL(finalize_dw_k<1>, dim3(blocks), dim3(64), 0, st, ws, dwo.out, L, S, taps, Cout, Cin, dwo.cout, dwo.cin, gain, dwo.accumulate);
     else if (S <= 64)
-        hipLaunchKernelGGL(finalize_dw_k<4>, dim3(blocks), dim3(256), 0, st, ws, dwo.out, L, S, taps, Cout, Cin, dwo.cout, dwo.cin, gain);
+        hipLaunchKernelGGL(finalize_dw_k<4>, dim3(blocks), dim3(256), 0, st, ws, dwo.out, L, S, taps, Cout, Cin, dwo.cout, dwo.cin, gain, dwo.accumulate);
     else
-        hipLaunchKernelGGL(finalize_dw_k<16>, dim3(blocks), dim3(1024), 0, st, ws, dwo.out, L, S, taps, Cout, Cin, dwo.cout, dwo.cin, gain);
+        hipLaunchKernelGGL(finalize_dw_k<16>, dim3(blocks), dim3(1024), 0, st, ws, dwo.out, L, S, taps, Cout, Cin, dwo.cout, dwo.cin, gain, dwo.accumulate);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         gan_set_error("finalize_dw: launch failed: %s", hipGetErrorString(e));

@@ -419,7 +419,8 @@ __global__ void __launch_bounds__(TPB) chan_dot_k(const T* __restrict__ A, const
 // sample; batch sums: G = 1, rows = N * blocks).  A workgroup = RG row lanes x CW channel vectors of V floats (RG a power
 // of two sized to the row count by the launcher); row lanes are folded by a tree through LDS, in a fixed order.
 template <int V>
-__global__ void __launch_bounds__(TPB) chan_fold_k(const float* __restrict__ part, float* __restrict__ out, int rows, int C, int CW, int RG) {
+__global__ void __launch_bounds__(TPB) chan_fold_k(const float* __restrict__ part, float* __restrict__ out, int rows, int C, int CW, int RG,
+                                                   int accum) {
     __shared__ float red[TPB * V];
     const int tc = threadIdx.x % CW, tr = threadIdx.x / CW;
     const int c = (blockIdx.x * CW + tc) * V;
@@ -449,7 +450,7 @@ __global__ void __launch_bounds__(TPB) chan_fold_k(const float* __restrict__ par
     }
     if (tr == 0 && c < C) {
 #pragma unroll
-        for (int e = 0; e < V; ++e) out[g * C + c + e] = red[threadIdx.x * V + e];
+        for (int e = 0; e < V; ++e) out[g * C + c + e] = (accum ? out[g * C + c + e] : 0.f) + red[threadIdx.x * V + e];
     }
 }
 
@@ -480,11 +481,11 @@ static ChanDotPlan chan_dot_plan(int N, int64_t HW, int C) {
 
 template <typename T>
 static int chan_dot_launch(const void* A, const void* B, int b_mode, const void* ymask, float slope, float* out,
-                           int64_t out_sn, int N, int64_t HW, int C, float* ws, hipStream_t st) {
+                           int64_t out_sn, int N, int64_t HW, int C, float* ws, int accum, hipStream_t st) {
     constexpr int VV = VecOf<T>::V;
     const ChanDotPlan pl = chan_dot_plan<T>(N, HW, C);
     GAN_CHECK_ARG(N <= 65535 && pl.zchunks <= 65535, "chan_dot: N or C too large for the grid");
-    const bool direct = out_sn != 0 && pl.bps == 1;  // one workgroup per (sample, channel chunk): its row IS the result
+    const bool direct = out_sn != 0 && pl.bps == 1 && !accum;  // one workgroup per (sample, channel chunk): its row IS the result
     float* part = direct ? out : ws;
     dim3 grid((unsigned)pl.bps, (unsigned)N, (unsigned)pl.zchunks);
     if (pl.V == VV)
@@ -503,9 +504,9 @@ static int chan_dot_launch(const void* A, const void* B, int b_mode, const void*
     if (CW > cvf) CW = cvf;
     const dim3 fgrid((unsigned)((cvf + CW - 1) / CW), (unsigned)(out_sn ? N : 1));
     if (FV == 4)
-        hipLaunchKernelGGL(chan_fold_k<4>, fgrid, dim3(TPB), 0, st, ws, out, rows, C, CW, RG);
+        hipLaunchKernelGGL(chan_fold_k<4>, fgrid, dim3(TPB), 0, st, ws, out, rows, C, CW, RG, accum);
     else
-        hipLaunchKernelGGL(chan_fold_k<1>, fgrid, dim3(TPB), 0, st, ws, out, rows, C, CW, RG);
+        hipLaunchKernelGGL(chan_fold_k<1>, fgrid, dim3(TPB), 0, st, ws, out, rows, C, CW, RG, accum);
     GAN_CHECK_LAUNCH("chan_dot(fold)");
     return GAN_OK;
 }
@@ -517,8 +518,9 @@ extern "C" int64_t gan_chan_dot_workspace(int N, int64_t HW, int C, int dtype) {
 }
 
 extern "C" int gan_chan_dot(const void* A, const void* B, int b_mode, const void* ymask, float slope, float* out,
-                            int64_t out_stride_n, int N, int64_t HW, int C, float* workspace, int64_t workspace_floats, int dtype,
-                            gan_stream_t stream) {
+                            int64_t out_stride_n, int N, int64_t HW, int C, float* workspace, int64_t workspace_floats, int accumulate,
+                            int dtype, gan_stream_t stream) {
+    GAN_CHECK_ARG(accumulate == 0 || accumulate == 1, "chan_dot: accumulate must be 0 or 1");
     GAN_CHECK_ARG(N >= 0 && HW >= 0 && C > 0, "chan_dot: bad shape");
     GAN_CHECK_ARG((A || N == 0 || HW == 0) && (out || (out_stride_n && N == 0)), "chan_dot: null pointer");
     GAN_CHECK_ARG(b_mode >= 0 && b_mode <= 2 && ((b_mode == 0) == (B == nullptr)), "chan_dot: b_mode %d vs B", b_mode);
@@ -528,6 +530,7 @@ extern "C" int gan_chan_dot(const void* A, const void* B, int b_mode, const void
     const size_t bytes = sizeof(float) * (size_t)(out_stride_n ? (int64_t)N * C : C);
     if (bytes == 0) return GAN_OK;
     if (N == 0 || HW == 0) {
+        if (accumulate) return GAN_OK;
         if (hipMemsetAsync(out, 0, bytes, st) != hipSuccess) {
             gan_set_error("chan_dot: memset failed");
             return GAN_ERR_LAUNCH;
@@ -536,8 +539,8 @@ extern "C" int gan_chan_dot(const void* A, const void* B, int b_mode, const void
     }
     GAN_CHECK_ARG(workspace != nullptr && workspace_floats >= gan_chan_dot_workspace(N, HW, C, dtype),
                   "chan_dot: needs a workspace of gan_chan_dot_workspace(...) = %lld floats", (long long)gan_chan_dot_workspace(N, HW, C, dtype));
-    if (dtype == GAN_F32) return chan_dot_launch<float>(A, B, b_mode, ymask, slope, out, out_stride_n, N, HW, C, workspace, st);
-    return chan_dot_launch<bf16>(A, B, b_mode, ymask, slope, out, out_stride_n, N, HW, C, workspace, st);
+    if (dtype == GAN_F32) return chan_dot_launch<float>(A, B, b_mode, ymask, slope, out, out_stride_n, N, HW, C, workspace, accumulate, st);
+    return chan_dot_launch<bf16>(A, B, b_mode, ymask, slope, out, out_stride_n, N, HW, C, workspace, accumulate, st);
 }
 
 // =========================================================================================

@@ -19,6 +19,7 @@ these primitives.
 """
 from __future__ import annotations
 
+import contextlib
 import weakref
 from typing import Dict, Optional, Tuple
 
@@ -204,8 +205,9 @@ def raw_mask_scale(g: Tensor, ymask: Optional[Tensor], a: Optional[Tensor], slop
     return out
 
 
-def raw_chan_dot(A: Tensor, B: Optional[Tensor], b_mode: int, ymask: Optional[Tensor], slope: float, per_sample: bool) -> Tensor:
-    """fp32 (N, C) if per_sample else (C,)."""
+def raw_chan_dot(A: Tensor, B: Optional[Tensor], b_mode: int, ymask: Optional[Tensor], slope: float, per_sample: bool,
+                 into: Optional[Tensor] = None) -> Tensor:
+    """fp32 (N, C) if per_sample else (C,).  `into`: an fp32 buffer of that many elements the sums are ADDED to."""
     require_gpu(A, B, ymask)
     lib = _lib.load()
     A = as_cl(A.detach())
@@ -220,14 +222,16 @@ def raw_chan_dot(A: Tensor, B: Optional[Tensor], b_mode: int, ymask: Optional[Te
     if ymask is not None:
         ymask = as_cl(ymask.detach().to(A.dtype))
     # two deterministic stages in the library (partial rows -> fold): the batch sum comes out of the same call
-    out = torch.empty((n, c) if per_sample else (c,), dtype=torch.float32, device=A.device)
+    if into is not None:
+        assert into.dtype == torch.float32 and into.is_contiguous() and into.numel() == (n * c if per_sample else c)
+    out = into if into is not None else torch.empty((n, c) if per_sample else (c,), dtype=torch.float32, device=A.device)
     ws_floats = lib.gan_chan_dot_workspace(n, h * w, c, dtype_code(A))
     ws = torch.empty((max(ws_floats, 1),), dtype=torch.float32, device=A.device)
     check(
         _run(
             "chan_dot", 0, _nbytes(A, B, ymask),
             lambda: lib.gan_chan_dot(ptr(A), ptr(B), b_mode, ptr(ymask), float(slope), ptr(out), c if per_sample else 0, n, h * w, c, ptr(ws), ws_floats,
-                                     dtype_code(A), stream_of(A)),
+                                     int(into is not None), dtype_code(A), stream_of(A)),
             (n, c, h, w, b_mode, int(ymask is not None), int(per_sample)),
         ),
         "gan_chan_dot",
@@ -582,10 +586,10 @@ def raw_conv2d_dgrad(
 
 def raw_conv2d_wgrad(
     x: Tensor, gy: Tensor, kh: int, kw: int, py: int, px: int, *, up2: bool = False, in_scale: Optional[Tensor] = None,
-    x_slope: float = 1.0, pooled: bool = False,
+    x_slope: float = 1.0, pooled: bool = False, into: Optional[Tensor] = None,
 ) -> Tensor:
     """fp32 (Cout, Cin, kh, kw).  x_slope: x goes through leaky-ReLU first; pooled: gy is the gradient of the
-    2x2-average-pooled output (half resolution)."""
+    2x2-average-pooled output (half resolution); into: an fp32 (Cout, Cin, kh, kw) buffer the gradient is ADDED to."""
     require_gpu(x, gy, in_scale)
     lib = _lib.load()
     cin, cout = x.shape[1], gy.shape[1]
@@ -600,7 +604,9 @@ def raw_conv2d_wgrad(
         in_scale = _f32(in_scale).reshape(n, cin)
         if cin_p != cin:
             in_scale = F.pad(in_scale, (0, cin_p - cin)).contiguous()
-    dw = torch.empty((cout, cin, kh, kw), dtype=torch.float32, device=x.device)
+    if into is not None:
+        assert into.dtype == torch.float32 and into.is_contiguous() and tuple(into.shape) == (cout, cin, kh, kw)
+    dw = into if into is not None else torch.empty((cout, cin, kh, kw), dtype=torch.float32, device=x.device)
     # split-K partials go to a caller-owned workspace (the library never allocates); torch's caching
     # allocator hands the same block back every step.  The slice reducer writes dw in the parameter's layout.
     ws_floats = lib.gan_conv2d_wgrad_workspace(n, h, w, cin_p, int(up2), ho, wo, cout_p, kh, kw, py, px, dtype_code(x))
@@ -612,7 +618,7 @@ def raw_conv2d_wgrad(
             "conv2d_wgrad_thin" if thin_w else "conv2d_wgrad", 2.0 * n * ho * wo * cout * cin * kh * kw, _nbytes(x, gy, dw),
             lambda: lib.gan_conv2d_wgrad(
                 ptr(x), ptr(gy), ptr(dw), cout, cin, ptr(in_scale), n, h, w, cin_p, int(up2), ho, wo, cout_p, kh, kw, py, px,
-                ptr(ws), ws_floats, float(x_slope), int(pooled), 0.25 if pooled else 1.0, dtype_code(x), stream_of(x)
+                ptr(ws), ws_floats, float(x_slope), int(pooled), 0.25 if pooled else 1.0, int(into is not None), dtype_code(x), stream_of(x)
             ),
             (n, cin, ho, wo, cout, kh, int(up2), int(pooled)),
         ),
@@ -644,6 +650,55 @@ def raw_ema_lerp(ema_flat: Tensor, p_flat: Tensor, weight: float) -> None:
 # ======================================================================================
 def _need(ctx, i: int) -> bool:
     return ctx.needs_input_grad[i]
+
+
+# ---- parameter gradients added into their buffers by the kernels that compute them -------------------------
+# autograd sums the contributions a parameter receives in one backward pass with one `add` launch per extra
+# contribution and tensor (a discriminator weight gets three per step: the real batch, the fake batch, R1's
+# second-order path): ~75 weight-sized launches per iteration.  Inside `direct_param_grads()`, a backward pass that
+# is not itself recorded (no create_graph) hands conv weights / biases whose `.grad` is already an fp32 buffer to
+# the split-K fold / channel-sum kernels with accumulate = 1 and returns None for them: same sums, no launches.
+# Parameter hooks do not see these gradients (post-accumulate hooks never fire), so the hook-driven bucketed
+# all-reduce path leaves this off; the trainer's graph path (flat all-reduce after the pass) turns it on.
+_DIRECT_PARAM_GRADS = False
+
+
+@contextlib.contextmanager
+def direct_param_grads(enabled: bool = True):
+    global _DIRECT_PARAM_GRADS
+    prev, _DIRECT_PARAM_GRADS = _DIRECT_PARAM_GRADS, enabled
+    try:
+        yield
+    finally:
+        _DIRECT_PARAM_GRADS = prev
+
+
+def grad_slot(p: Optional[Tensor]) -> Optional[Tensor]:
+    """p.grad when the current backward pass may add p's gradient straight into it, else None."""
+    if not _DIRECT_PARAM_GRADS or p is None or torch.is_grad_enabled() or not isinstance(p, torch.nn.Parameter):
+        return None
+    g = p.grad
+    if g is None or g.dtype != torch.float32 or not g.is_contiguous() or g.shape != p.shape or not g.is_cuda:
+        return None
+    return g
+
+
+def _wgrad_for(w: Tensor, x: Tensor, gy: Tensor, py: int, px: int, x_slope: float = 1.0, pool: bool = False) -> Optional[Tensor]:
+    """The gradient of conv weight w (Conv2dWgradFn), or None after adding it into w.grad (grad_slot)."""
+    slot = grad_slot(w)
+    if slot is not None:
+        raw_conv2d_wgrad(x, gy, w.shape[2], w.shape[3], py, px, x_slope=x_slope, pooled=pool, into=slot)
+        return None
+    return Conv2dWgradFn.apply(x, gy, w.shape[2], w.shape[3], py, px, x_slope, pool).to(w.dtype)
+
+
+def _bias_grad_for(b: Tensor, g: Tensor) -> Optional[Tensor]:
+    """The gradient of a per-channel bias (ChanSumFn over the batch), or None after adding it into b.grad."""
+    slot = grad_slot(b)
+    if slot is not None and slot.numel() == g.shape[1]:
+        raw_chan_dot(g, None, 0, None, 1.0, False, into=slot)
+        return None
+    return ChanSumFn.apply(g, False).reshape(b.shape).to(b.dtype)
 
 
 class UpFirDnFn(Function):
@@ -807,7 +862,7 @@ class Conv2dFn(Function):
         gx = Conv2dDgradFn.apply(gy, weight, py, px, xaux, in_slope, pool) if _need(ctx, 0) else None
         gw = None
         if _need(ctx, 1):
-            gw = Conv2dWgradFn.apply(x, gy, weight.shape[2], weight.shape[3], py, px, in_slope, pool).to(weight.dtype)
+            gw = _wgrad_for(weight, x, gy, py, px, in_slope, pool)
         return gx, gw, None, None, None, None
 
 
@@ -830,7 +885,7 @@ class Conv2dDgradFn(Function):
         g_gy = Conv2dFn.apply(z, weight, py, px, 1.0, pool).to(gy.dtype) if _need(ctx, 0) else None
         g_w = None
         if _need(ctx, 1):
-            g_w = Conv2dWgradFn.apply(z, gy, weight.shape[2], weight.shape[3], py, px, 1.0, pool).to(weight.dtype)
+            g_w = _wgrad_for(weight, z, gy, py, px, 1.0, pool)
         g_resid = ggx if len(ctx.needs_input_grad) > 7 and ctx.needs_input_grad[7] else None
         return g_gy, g_w, None, None, None, None, None, g_resid
 
@@ -871,14 +926,14 @@ class DBlockInputFn(Function):
                 gx_s = UpFirDnFn.apply(Conv2dDgradFn.apply(g_s, ws, 0, 0), _ones_taps(x, 0.25), 2, 1, 1, 0, 1, 0)
             gx = Conv2dDgradFn.apply(g_p1, w1, pad, pad, x, slope, False, gx_s)
         if _need(ctx, 1):
-            gw1 = Conv2dWgradFn.apply(x, g_p1, w1.shape[2], w1.shape[3], pad, pad, slope, False).to(w1.dtype)
+            gw1 = _wgrad_for(w1, x, g_p1, pad, pad, slope, False)
         if b1 is not None and _need(ctx, 2):
-            gb1 = ChanSumFn.apply(g_p1, False).reshape(b1.shape).to(b1.dtype)
+            gb1 = _bias_grad_for(b1, g_p1)
         if _need(ctx, 3):
             if pool_in_conv:
-                gws = Conv2dWgradFn.apply(x, g_s, 1, 1, 0, 0, 1.0, True).to(ws.dtype)
+                gws = _wgrad_for(ws, x, g_s, 0, 0, 1.0, True)
             else:
-                gws = Conv2dWgradFn.apply(xs, g_s, 1, 1, 0, 0).to(ws.dtype)
+                gws = _wgrad_for(ws, xs, g_s, 0, 0)
         return gx, gw1, gb1, gws, None, None, gbs
 
 
@@ -1041,10 +1096,10 @@ class ConvBiasActFn(Function):
         gx = Conv2dDgradFn.apply(gz, weight, pad, pad, xaux, in_slope, pool) if _need(ctx, 0) else None
         gw = None
         if _need(ctx, 1):
-            gw = Conv2dWgradFn.apply(x, gz, weight.shape[2], weight.shape[3], pad, pad, in_slope, pool).to(weight.dtype)
+            gw = _wgrad_for(weight, x, gz, pad, pad, in_slope, pool)
         gb = None
         if bias is not None and _need(ctx, 2):
-            gb = ChanSumFn.apply(gz, False).reshape(bias.shape).to(bias.dtype)
+            gb = _bias_grad_for(bias, gz)
         return gx, gw, gb, None, None, None, None
 
 

@@ -113,7 +113,9 @@ class ModConvFn(Function):
             else:
                 gx = GF.raw_mask_scale(gxs, None, s, 1.0) if s is not None else gxs
         if need[1]:
-            gw = GF.raw_conv2d_wgrad(x, gz, kh, kh, pad, pad, up2=up2, in_scale=s).to(weight.dtype)
+            slot = GF.grad_slot(weight)  # a buffer the fold kernel adds to (functional.py: direct_param_grads), or None
+            gw = GF.raw_conv2d_wgrad(x, gz, kh, kh, pad, pad, up2=up2, in_scale=s, into=slot)
+            gw = None if slot is not None else gw.to(weight.dtype)
         return gx, gw, gs, gdinv, gb, None, gns, None, None
 
     @staticmethod

@@ -265,8 +265,9 @@ class Trainer:
                 if last and overlap:
                     self.red_d.prepare()
                 if a == 0 and not overlap:
-                    self.red_d.arena.detach_grads()
-                loss_d.backward()
+                    self.red_d.arena.begin_direct()
+                with GF.direct_param_grads(not overlap):  # (the hook-driven exchange needs autograd's accumulation step)
+                    loss_d.backward()
                 if last:
                     if overlap:
                         self.red_d.finish()
@@ -296,8 +297,9 @@ class Trainer:
                 if last and overlap:
                     self.red_g.prepare()
                 if a == 0 and not overlap:
-                    self.red_g.arena.detach_grads()
-                loss_g.backward()
+                    self.red_g.arena.begin_direct()
+                with GF.direct_param_grads(not overlap):
+                    loss_g.backward()
                 if last and overlap:
                     self.red_g.finish()
         finally:

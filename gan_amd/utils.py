@@ -127,6 +127,21 @@ class FlatArena:
         for p in self.params:
             p.grad = None
 
+    def begin_direct(self, select=lambda p: p.dim() == 4) -> None:
+        """Before a backward pass run under functional.direct_param_grads(): the parameters `select` picks (conv
+        weights: the tensors whose gradients the wgrad kernels can add in place) get their ZEROED arena slices as
+        .grad, every other parameter None (autograd then hands its first gradient over for free); gather_grads()
+        files the rest afterwards."""
+        views = []
+        for p, o in zip(self.params, self.offsets):
+            if p.requires_grad and select(p):
+                p.grad = self.grad[o : o + p.numel()].view(p.shape)
+                views.append(p.grad)
+            else:
+                p.grad = None
+        if views:
+            torch._foreach_zero_(views)
+
     def gather_grads(self) -> None:
         views, srcs, missing = [], [], False
         for p, o in zip(self.params, self.offsets):

@@ -79,11 +79,13 @@ int gan_mask_scale(const void* g, const void* ymask, const float* a, int64_t a_s
  * out_stride_n = C gives per-sample sums [N][C]; out_stride_n = 0 gives batch sums [C].
  * Two deterministic stages (wavefront shuffle + LDS reduction per workgroup, partial rows stored to `workspace`, a fold
  * kernel that sums them in a fixed order): no atomics, `out` need not be zeroed, every element of it is written.
+ * accumulate = 1: out += the sums instead (a parameter's gradient buffer that other passes have already written to:
+ * autograd's accumulation step, torch/csrc/autograd/functions/accumulate_grad.h, without its launch per tensor).
  * workspace: at least gan_chan_dot_workspace(N, HW, C, dtype) floats, caller-owned (the library never allocates). */
 int64_t gan_chan_dot_workspace(int N, int64_t HW, int C, int dtype);
 int gan_chan_dot(const void* A, const void* B, int b_mode, const void* ymask, float slope, float* out,
-                 int64_t out_stride_n, int N, int64_t HW, int C, float* workspace, int64_t workspace_floats, int dtype,
-                 gan_stream_t stream);
+                 int64_t out_stride_n, int N, int64_t HW, int C, float* workspace, int64_t workspace_floats, int accumulate,
+                 int dtype, gan_stream_t stream);
 
 /* Fused passes of the modulated convolution's backward (autograd of ModulatedConv2d.forward,
  * modelling/stylegan2.py:29-36; they replace three gan_chan_dot calls + one gan_mask_scale, and one of each):
@@ -155,12 +157,14 @@ int gan_conv2d_fwd(const void* x, const void* wt, void* y, const float* in_scale
  *   x_slope != 1 : X = leaky_relu(x, x_slope) as it is staged (before in_scale);
  *   gy_up2 = 1   : gy is [N][Ho/2][Wo/2][Cout] and read through a nearest-neighbour 2x gather (the adjoint
  *                  of the pooling, together with gain = 0.25);
- *   gain         : scalar factor on dw.  Pass 1, 0, 1 for none. */
+ *   gain         : scalar factor on dw.  Pass 1, 0, 1 for none.
+ * accumulate = 1: dw += the gradient instead of dw = (as gan_chan_dot's flag: the fold kernel reads dw back). */
 int64_t gan_conv2d_wgrad_workspace(int N, int H, int W, int Cin, int up2, int Ho, int Wo, int Cout, int kh, int kw,
                                    int py, int px, int dtype);
 int gan_conv2d_wgrad(const void* x, const void* gy, float* dw, int Cout_out, int Cin_out, const float* in_scale, int N, int H, int W, int Cin,
                      int up2, int Ho, int Wo, int Cout, int kh, int kw, int py, int px, float* workspace,
-                     int64_t workspace_floats, float x_slope, int gy_up2, float gain, int dtype, gan_stream_t stream);
+                     int64_t workspace_floats, float x_slope, int gy_up2, float gain, int accumulate, int dtype,
+                     gan_stream_t stream);
 
 /* The same weight gradient for callers that cannot allocate (code under HIP graph capture, tight serving loops,
  * harnesses that forbid hipMalloc).  NO counterpart in the reference: the reference allocates freely through

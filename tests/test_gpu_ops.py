@@ -917,3 +917,53 @@ def test_rgb_conv1x1_family(dev, case, out_dtype, x_dtype, layout):
     g2r = torch.autograd.grad(gr[0].square().sum() + gr[1].square().sum(), [wr, xr])
     for a, r_, nm in zip(g2, g2r, "wx"):
         assert rel_err(a, r_) < 3 * tol2, (nm, rel_err(a, r_))
+
+
+def test_accumulate_into_gradient_buffers(dev):
+    """accumulate = 1 of gan_conv2d_wgrad / gan_chan_dot: the result is ADDED to the caller's fp32 buffer (every wgrad
+    path: thin, tiled, register-staged), and GF.direct_param_grads() makes a plain backward pass use it for conv
+    weights and biases whose .grad is already a buffer -- the same gradients as autograd's own accumulation."""
+    import gan_amd.functional as GF
+
+    torch.manual_seed(43)
+    for n, cin, h, w, cout, k, dt in [(4, 16, 64, 64, 32, 3, torch.bfloat16), (4, 128, 16, 16, 256, 3, torch.bfloat16),
+                                      (3, 24, 9, 7, 40, 3, torch.float32), (2, 512, 4, 4, 1, 4, torch.bfloat16)]:
+        pad = (k - 1) // 2 if k != 4 else 0
+        x = torch.randn(n, cin, h, w, device=dev).to(dt)
+        gy = torch.randn(n, cout, h + 2 * pad - k + 1, w + 2 * pad - k + 1, device=dev).to(dt)
+        base = torch.randn(cout, cin, k, k, device=dev)
+        ref = GF.raw_conv2d_wgrad(x, gy, k, k, pad, pad)
+        got = base.clone()
+        assert GF.raw_conv2d_wgrad(x, gy, k, k, pad, pad, into=got) is got
+        assert rel_err(got - base, ref) < 1e-5, (n, cin, h, w, cout, k)
+    a = torch.randn(5, 48, 20, 12, device=dev).bfloat16()
+    b = torch.randn_like(a)
+    for per_sample in (False, True):
+        base = torch.randn((5, 48) if per_sample else (48,), device=dev)
+        ref = GF.raw_chan_dot(a, b, 1, None, 1.0, per_sample)
+        got = base.clone()
+        GF.raw_chan_dot(a, b, 1, None, 1.0, per_sample, into=got)
+        assert rel_err(got - base, ref) < 1e-5
+
+    # a plain backward through conv + bias + activation, the weight used twice: .grad preset to a buffer
+    conv_w = torch.nn.Parameter(torch.randn(32, 16, 3, 3, device=dev) * 0.1)
+    conv_b = torch.nn.Parameter(torch.randn(32, device=dev) * 0.1)
+    x = torch.randn(4, 16, 32, 32, device=dev).bfloat16()
+
+    def loss():
+        y1 = GF.ConvBiasActFn.apply(x, conv_w, conv_b, 1, 0.2)
+        y2 = GF.ConvBiasActFn.apply(x * 0.5, conv_w, conv_b, 1, 0.2)
+        return (y1.float().square().mean() + y2.float().mean())
+
+    loss().backward()
+    ref_w, ref_b = conv_w.grad.clone(), conv_b.grad.clone()
+    seed_w, seed_b = torch.randn_like(ref_w), torch.randn_like(ref_b)
+    conv_w.grad, conv_b.grad = seed_w.clone(), seed_b.clone()
+    with GF.direct_param_grads():
+        loss().backward()
+    assert rel_err(conv_w.grad - seed_w, ref_w) < 1e-5 and rel_err(conv_b.grad - seed_b, ref_b) < 1e-5
+    # under create_graph the pass is recorded and must not touch the buffers
+    conv_w.grad, conv_b.grad = seed_w.clone(), seed_b.clone()
+    with GF.direct_param_grads():
+        (gw,) = torch.autograd.grad(loss(), conv_w, create_graph=True)
+    assert torch.equal(conv_w.grad, seed_w) and rel_err(gw, ref_w) < 1e-5

@@ -43,7 +43,7 @@ def _call(lib, static, x, gy, k, dw):
     else:
         need = lib.gan_conv2d_wgrad_workspace(*shape_args, dtype_code(x))
         ws = torch.empty((max(need, 1),), dtype=torch.float32, device=dev)
-        check(lib.gan_conv2d_wgrad(ptr(x), ptr(gy), ptr(dw), cout, cin, None, *shape_args, ptr(ws), need, 1.0, 0, 1.0, dtype_code(x), stream_of(x)),
+        check(lib.gan_conv2d_wgrad(ptr(x), ptr(gy), ptr(dw), cout, cin, None, *shape_args, ptr(ws), need, 1.0, 0, 1.0, 0, dtype_code(x), stream_of(x)),
               "gan_conv2d_wgrad")
     return dw
 

@@ -67,4 +67,4 @@ for site, n in by_site.most_common(60):
     for (s2, name, shape), k in counts.items():
         if s2 == site:
             ops[f'{name[6:]}{shape}'] += k
-    print(f'{n:5d}  {site:58s} ' + ', '.join(f'{k}x{v}' for k, v in ops.most_common(4)))
+    print(f'{n:5d}  {site:58s} ' + ', '.join(f'{k}x{v}' for k, v in ops.most_common(40 if site.startswith("autograd") else 4)))
