@@ -482,6 +482,63 @@ def test_hip_graph_iteration_matches_eager(dev, monkeypatch):
         assert abs(a[0] - b[0]) <= 1e-2 * max(1.0, abs(b[0])) and abs(a[1] - b[1]) <= 1e-2 * max(1.0, abs(b[1])), (i, graphed, eager)
 
 
+def test_hip_graph_capture_failure_falls_back_to_eager(dev, monkeypatch, capsys):
+    """A capture that raises after its first segment was recorded (never executed): the trainer must drop what the
+    aborted capture left behind -- packed weights and padded inputs in graph-pool buffers, handed-over gradient
+    tensors -- and run that step and the following ones from the host, with the losses of a trainer that never tried."""
+    from gan_amd.train_celeba import TrainConfig, Trainer
+
+    real_randn = torch.randn
+    cache = {}
+
+    def fixed_randn(*shape, **kw):
+        shape = tuple(shape[0]) if len(shape) == 1 and isinstance(shape[0], (tuple, list, torch.Size)) else tuple(shape)
+        key = (shape, str(kw.get("dtype")), str(kw.get("device")))
+        if key not in cache:
+            g = torch.Generator(device="cpu").manual_seed(len(cache) + 17)
+            cache[key] = real_randn(*shape, generator=g).to(device=kw.get("device"), dtype=kw.get("dtype") or torch.float32)
+        return cache[key]
+
+    real_graph = torch.cuda.graph
+    entered = {"n": 0}
+
+    class FailingGraph(real_graph):
+        def __enter__(self):
+            entered["n"] += 1
+            if entered["n"] == 2:
+                raise RuntimeError("capture refused (test)")
+            return super().__enter__()
+
+    def run(graph):
+        torch.manual_seed(9)
+        cfg = TrainConfig(model="stylegan2", img_size=32, gen_kwargs={"base_dim": 64}, disc_kwargs={"base_dim": 16},
+                          method="hinge", regularizer="r1", batch_size=8, optimizer="Adam", optimizer_kwargs={"betas": [0, 0.9]},
+                          lr=2e-4, device="cuda", mixed_precision=False, channels_last=False, hip_graph=graph, graph_warmup=1)
+        tr = Trainer(cfg, dev)
+        g = torch.Generator(device="cpu").manual_seed(5)
+        pool = [real_randn(8, 3, 32, 32, generator=g).to(dev) for _ in range(4)]
+        out = []
+        monkeypatch.setattr(torch, "randn", fixed_randn)
+        try:
+            for i in range(4):
+                logs = tr.train_step(lambda: pool[i])
+                out.append((float(logs["loss/d"]), float(logs["loss/g"])))
+        finally:
+            monkeypatch.setattr(torch, "randn", real_randn)
+        return out, tr
+
+    eager, _ = run(False)
+    monkeypatch.setattr(torch.cuda, "graph", FailingGraph)
+    try:
+        fallen, tr = run(True)
+    finally:
+        monkeypatch.setattr(torch.cuda, "graph", real_graph)
+    assert entered["n"] == 2 and tr._graph is None and tr.cfg.hip_graph is False
+    assert "continuing without graphs" in capsys.readouterr().err
+    for i, (a, b) in enumerate(zip(fallen, eager)):
+        assert abs(a[0] - b[0]) <= 1e-2 * max(1.0, abs(b[0])) and abs(a[1] - b[1]) <= 1e-2 * max(1.0, abs(b[1])), (i, fallen, eager)
+
+
 # ------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("name", ["stylegan", "progressive_gan"])
 def test_generators_v1_golden(dev, golden, name):
