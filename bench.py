@@ -292,8 +292,23 @@ def micro_leg(device):
         rec["timed_iters"] = n_iter
         del data
         torch.cuda.empty_cache()
+    # DiffAugment in front of the discriminator (diff_augment.py:54-60) at the headline batch: the reference's
+    # eight kernels as one sum pass + one apply pass.  Algorithmic bytes: the image read once and written once.
+    import gan_amd.diff_augment as DA
+
+    da = {}
+    for dt, tag in ((torch.float32, "f32_nchw"), (torch.bfloat16, "bf16_nhwc")):
+        imgs = torch.randn(256, 3, 256, 256, device=device, dtype=dt)
+        if dt == torch.bfloat16:
+            imgs = imgs.contiguous(memory_format=torch.channels_last)
+        usk = torch.rand(256, 3, device=device)
+        shift = torch.tensor([7, -5, 40, 90], dtype=torch.int32, device=device)
+        t = timeit(lambda: DA._raw_diffaug(imgs, usk, shift, 0), 50)
+        da[tag] = {"us": round(t * 1e6, 1), "gbs": round(2 * imgs.numel() * imgs.element_size() / t / 1e9, 1)}
+        da[tag]["frac"] = round(da[tag]["gbs"] / HBM_PEAK_GBS, 4)
+        del imgs
     big = out["32x16x1024x1024"]
-    return dict(shapes=out, peak_gbs=HBM_PEAK_GBS, fir3_frac_at_largest=round(big["fir3_gbs"] / HBM_PEAK_GBS, 4),
+    return dict(shapes=out, diff_augment_256x3x256x256=da, peak_gbs=HBM_PEAK_GBS, fir3_frac_at_largest=round(big["fir3_gbs"] / HBM_PEAK_GBS, 4),
                 bias_lrelu_frac_at_largest=round(big["bias_lrelu_gbs"] / HBM_PEAK_GBS, 4),
                 method="*_gbs: raw kernel launches, events over 100 (20) launches, algorithmic bytes (in + out) * 2; "
                        "its_per_s_n_backward: benchmark_upfirdn2d.py:15-29 on UpFIRDn2d.apply, bf16 channels_last")

@@ -6,7 +6,7 @@
         --optimizer Adam --optimizer_kwargs '{"betas":[0.0,0.9]}' --batch_size 64 --n_iters 100
     torchrun --nproc-per-node 8 -m gan_amd.train_celeba ... --batch_size 256     # global batch, sharded
 
-Out of scope here: the CelebA loader, wandb, PNG dumps, FID, DiffAugment.
+Out of scope here: the CelebA loader, wandb, PNG dumps, FID.
 """
 import json
 import os
@@ -70,13 +70,15 @@ class Trainer:
     """State of the loop in train_celeba.py:60-77 plus the data-parallel reducers."""
 
     def __init__(self, cfg: TrainConfig, device: Optional[torch.device] = None, world: int = 1, z_dim: int = 128):
-        if cfg.diff_augment:
-            raise NotImplementedError("DiffAugment is outside the hot path (SURVEY.md section 2 row 11)")
         self.cfg = cfg
         self.device = torch.device(device if device is not None else cfg.device)
         self.world = world
         self.z_dim = z_dim
         self.disc = build_discriminator(cfg.model, img_size=cfg.img_size, **cfg.disc_kwargs).to(self.device)
+        if cfg.diff_augment:  # train_celeba.py:63 (parameter names gain the "1." prefix there too)
+            from .diff_augment import DiffAugment
+
+            self.disc = nn.Sequential(DiffAugment(), self.disc)
         self.gen = build_generator(cfg.model, img_size=cfg.img_size, **cfg.gen_kwargs).to(self.device)
         prepare_model(self.disc, spectral_norm=cfg.sn_disc, channels_last=cfg.channels_last, compile=cfg.compile)
         prepare_model(self.gen, spectral_norm=cfg.sn_gen, channels_last=cfg.channels_last, compile=cfg.compile)

@@ -247,6 +247,22 @@ int64_t gan_rgb_conv1x1_wgrad_workspace(int Cin, int Cout);
 int gan_rgb_conv1x1_wgrad(const void* x, int x_dtype, int64_t sn, int64_t sc, int64_t sh, int64_t sw, const void* gy, int gy_dtype, float* dw,
                           float* workspace, int64_t workspace_floats, int N, int Cin, int H, int W, int Cout, gan_stream_t stream);
 
+/* DiffAugment (diff_augment.py:13-60; train_celeba.py:63 puts it in front of the discriminator): brightness,
+ * saturation, contrast, translation and cut-out of an image batch as one affine map, applied in one pass after a
+ * per-sample sum (the reference: eight launches and as many round trips).
+ *   in   : [N, C, H, W] with element strides (sn, sc, sh, sw), C <= 4, fp32 or bf16 (`dtype`)
+ *   out  : [N][H][W][C] (channels-last, contiguous), same dtype
+ *   usk  : [N][3] device floats in [0, 1): the draws of rand_brightness / rand_saturation / rand_contrast (:14,19,24)
+ *   shift: 4 device ints (tx, ty, cy, cx): translate(x, tx, ty) (:35-36) and RandomCutout's (offset_y, offset_x) (:48-49);
+ *          the cut-out is H/2 x H/2 as in the reference (:50)
+ *   mode : 0 = the augmentation y = A x + c;  1 = its linear part y = A x (the gradient of mode 2);
+ *          2 = its adjoint y = A' x (the gradient of modes 0 and 1) -- closed under differentiation, as R1 needs.
+ * Every draw is read on the device, so the call can be captured in a HIP graph (the reference's `.item()` cannot).
+ * workspace: gan_diffaug_workspace(N) floats, caller-owned, contents undefined on entry and exit. */
+int64_t gan_diffaug_workspace(int N);
+int gan_diffaug(const void* in, int64_t sn, int64_t sc, int64_t sh, int64_t sw, void* out, const float* usk, const int* shift, int mode, int N,
+                int C, int H, int W, float* workspace, int64_t workspace_floats, int dtype, gan_stream_t stream);
+
 /* ---- stride-2 convolutions as stride-1 convolutions ------------------------------------------------------------
  * replaces the stride of nn.Conv2d(k, 2, p) / nn.ConvTranspose2d(k, 2, p) with even k in DCGAN (modelling/dcgan.py:21-29,
  * 50-60 through conv_norm_act, modelling/common.py:46-70): Conv_s2(x; W) = ValidConv_{k/2}(S2D_p(x); W') with

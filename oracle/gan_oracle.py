@@ -345,6 +345,24 @@ def dcgan_generator(sd: Mapping[str, Tensor], z: Tensor) -> Tensor:
 # --------------------------------------------------------------------------------------
 # losses.py
 # --------------------------------------------------------------------------------------
+def diff_augment(x: Tensor, brightness: Tensor, saturation: Tensor, contrast: Tensor, translate_x: int, translate_y: int,
+                 offset_y: int, offset_x: int) -> Tensor:
+    """DiffAugment (diff_augment.py:54-60) with its random draws made explicit: `brightness` / `saturation` / `contrast` are
+    the torch.rand(N, 1, 1, 1) values of :14, :19, :24; the integers those of :42 (x, then y) and :48-49 (y, then x)."""
+    n = x.shape[0]
+    b, s, k = (t.reshape(n, 1, 1, 1).to(x.dtype) for t in (brightness, saturation, contrast))
+    x = x + b - 0.5                                            # rand_brightness :13-14
+    mean = x.mean(dim=-3, keepdim=True)
+    x = mean + (x - mean) * s * 2                              # rand_saturation :17-19
+    mean = x.mean(dim=[-1, -2, -3], keepdim=True)
+    x = mean + (x - mean) * (k + 0.5)                          # rand_contrast :22-24
+    x = F.pad(x, (translate_x, -translate_x, translate_y, -translate_y))  # translate :35-36
+    h = x.shape[-2]
+    mask = torch.ones_like(x)                                  # RandomCutout :45-51 (H // 2 for both sides, as written there)
+    mask[..., offset_y : offset_y + h // 2, offset_x : offset_x + h // 2] = 0
+    return x * mask
+
+
 def d_loss(method: str, d_reals: Tensor, d_fakes: Tensor) -> Tensor:
     """losses.py:27-83, discriminator side."""
     if method == "gan":

@@ -27,6 +27,7 @@ sys.path.insert(1, REPO)
 import torch  # noqa: E402
 from torch import nn  # noqa: E402
 
+import diff_augment as ref_da  # noqa: E402  (reference)
 import losses as ref_losses  # noqa: E402  (reference)
 import utils as ref_utils  # noqa: E402  (reference)
 from modelling import build_discriminator, build_generator  # noqa: E402  (reference)
@@ -461,6 +462,42 @@ def gold_resample_convs():
     save("resample_convs", out)
 
 
+def gold_diff_augment():
+    """DiffAugment (diff_augment.py:54-60) and its pieces on CPU: the draws the reference makes from the global generator
+    are recovered by re-seeding and drawing in the same order (:14, :19, :24 -> torch.rand(N, 1, 1, 1); :42 -> x then y;
+    :48-49 -> y then x).  Output, gradient of a weighted + quadratic loss in x, and the gradient of that gradient's norm."""
+    out = {}
+    for tag, shape, seed in (("rgb16", (4, 3, 16, 16), 101), ("rgb24x40", (3, 3, 24, 40), 102), ("gray8", (2, 1, 8, 8), 103), ("rgb32", (2, 3, 32, 32), 104)):
+        n, c, h, w = shape
+        g = torch.Generator().manual_seed(seed)
+        x0 = torch.randn(shape, generator=g)
+        wgt = torch.randn(shape, generator=g)
+        x = x0.clone().requires_grad_(True)
+        torch.manual_seed(seed)
+        y = ref_da.DiffAugment()(x)
+        torch.manual_seed(seed)
+        b, s, k = (torch.rand(n, 1, 1, 1) for _ in range(3))
+        tx, ty = ref_da.rand_int(-(w // 8), w // 8 + 1), ref_da.rand_int(-(h // 8), h // 8 + 1)
+        oy, ox = ref_da.rand_int(0, h // 2), ref_da.rand_int(0, w // 2)
+        loss = (y * wgt).sum() + y.square().mean()
+        (g1,) = torch.autograd.grad(loss, x, create_graph=True)
+        (g2,) = torch.autograd.grad(g1.square().sum(), x)
+        assert torch.allclose(O.diff_augment(x0, b, s, k, tx, ty, oy, ox), y.detach(), atol=1e-6), tag
+        pieces = {}
+        for name, fn in () if tag != "rgb16" else (("brightness", ref_da.rand_brightness), ("saturation", ref_da.rand_saturation), ("contrast", ref_da.rand_contrast)):
+            torch.manual_seed(seed + 7)
+            pieces[name] = {"y": fn(x0.clone()), "u": None}
+            torch.manual_seed(seed + 7)
+            pieces[name]["u"] = torch.rand(n, 1, 1, 1)
+        if tag == "rgb16":
+            pieces["translate"] = {"y": ref_da.translate(x0.clone(), tx, ty)}
+        out[tag] = {
+            "x": x0, "wgt": wgt, "brightness": b, "saturation": s, "contrast": k, "translate": (tx, ty), "cutout": (oy, ox),
+            "y": y.detach().clone(), "loss": float(loss.detach()), "grad": g1.detach().clone(), "grad2": g2.detach().clone(), "pieces": pieces,
+        }
+    save("diff_augment", out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     if len(sys.argv) > 1:  # regenerate only the named fixtures: python oracle/make_goldens.py resample_convs
@@ -476,3 +513,4 @@ if __name__ == "__main__":
     gold_trajectory()
     gold_resample_convs()
     gold_generators_v1()
+    gold_diff_augment()

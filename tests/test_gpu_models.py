@@ -539,6 +539,28 @@ def test_hip_graph_capture_failure_falls_back_to_eager(dev, monkeypatch, capsys)
         assert abs(a[0] - b[0]) <= 1e-2 * max(1.0, abs(b[0])) and abs(a[1] - b[1]) <= 1e-2 * max(1.0, abs(b[1])), (i, fallen, eager)
 
 
+def test_trainer_with_diff_augment(dev):
+    """TrainConfig.diff_augment (train_celeba.py:45,63): the discriminator wrapped in nn.Sequential(DiffAugment(), disc),
+    hinge + R1 differentiating through the augmentation twice, launched from the host and replayed as HIP graphs."""
+    from gan_amd.diff_augment import DiffAugment
+    from gan_amd.train_celeba import TrainConfig, Trainer
+
+    for graph in (False, True):
+        torch.manual_seed(13)
+        cfg = TrainConfig(model="stylegan2", img_size=32, gen_kwargs={"base_dim": 64}, disc_kwargs={"base_dim": 16}, method="hinge",
+                          regularizer="r1", batch_size=8, optimizer="Adam", optimizer_kwargs={"betas": [0, 0.9]}, lr=2e-4, device="cuda",
+                          mixed_precision=True, channels_last=True, hip_graph=graph, graph_warmup=1, diff_augment=True)
+        tr = Trainer(cfg, dev)
+        assert isinstance(tr.disc[0], DiffAugment) and next(iter(tr.disc.state_dict())).startswith("1.")
+        reals = torch.randn(8, 3, 32, 32, device=dev)
+        before = [p.detach().clone() for p in tr.disc.parameters()]
+        for _ in range(3):
+            logs = tr.train_step(lambda: reals)
+        assert all(math.isfinite(float(v)) for v in logs.values())
+        assert any(not torch.equal(a, b) for a, b in zip(before, tr.disc.parameters()))
+        assert (tr._graph is not None) == graph
+
+
 # ------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("name", ["stylegan", "progressive_gan"])
 def test_generators_v1_golden(dev, golden, name):

@@ -967,3 +967,64 @@ def test_accumulate_into_gradient_buffers(dev):
     with GF.direct_param_grads():
         (gw,) = torch.autograd.grad(loss(), conv_w, create_graph=True)
     assert torch.equal(conv_w.grad, seed_w) and rel_err(gw, ref_w) < 1e-5
+
+
+def test_diff_augment_kernel(dev, golden, monkeypatch):
+    """gan_diffaug behind gan_amd.diff_augment (the reference's module API, diff_augment.py): the whole pipeline with the
+    reference's draws against the reference's output, gradient and second-order gradient (fp32 1e-5 / 1e-4); bf16 and
+    strided (NCHW and channels-last) inputs against the oracle; the standalone pieces with their draw pinned; and the
+    pass captured in a HIP graph (no host synchronisation: the reference's `.item()` draws would not capture)."""
+    import gan_amd.diff_augment as DA
+    from oracle import gan_oracle as O
+
+    gold = golden("diff_augment")
+    for tag, g in gold.items():
+        tx, ty = g["translate"]
+        oy, ox = g["cutout"]
+        draws = [g[k].to(dev) for k in ("brightness", "saturation", "contrast")]
+        for fmt in (torch.contiguous_format, torch.channels_last):
+            x = g["x"].to(dev).contiguous(memory_format=fmt).requires_grad_(True)
+            y = DA.diff_augment(x, *draws, tx, ty, oy, ox)
+            assert y.shape == g["y"].shape and y.dtype == torch.float32
+            assert rel_err(y, g["y"]) < TOL32, (tag, rel_err(y, g["y"]))
+            loss = (y * g["wgt"].to(dev)).sum() + y.square().mean()
+            (g1,) = torch.autograd.grad(loss, x, create_graph=True)
+            (g2,) = torch.autograd.grad(g1.square().sum(), x)
+            assert rel_err(g1, g["grad"]) < TOL32 and rel_err(g2, g["grad2"]) < TOL32_2, (tag, rel_err(g1, g["grad"]), rel_err(g2, g["grad2"]))
+        # bf16: the oracle on the bf16-rounded image, in fp64
+        xb = g["x"].bfloat16()
+        ref = O.diff_augment(xb.double(), g["brightness"].double(), g["saturation"].double(), g["contrast"].double(), tx, ty, oy, ox)
+        got = DA.diff_augment(xb.to(dev), *draws, tx, ty, oy, ox)
+        assert got.dtype == torch.bfloat16 and rel_err(got, ref) < 1e-2
+    # the pieces, with the one draw each makes pinned to the reference's
+    g = gold["rgb16"]
+    x = g["x"].to(dev)
+    real_rand = torch.rand
+    for name, fn in (("brightness", DA.rand_brightness), ("saturation", DA.rand_saturation), ("contrast", DA.rand_contrast)):
+        u = g["pieces"][name]["u"]
+        monkeypatch.setattr(torch, "rand", lambda *a, **k: u.to(device=k.get("device"), dtype=k.get("dtype") or torch.float32))
+        try:
+            got = fn(x)
+        finally:
+            monkeypatch.setattr(torch, "rand", real_rand)
+        assert rel_err(got, g["pieces"][name]["y"]) < TOL32, name
+    assert rel_err(DA.translate(x, *g["translate"]), g["pieces"]["translate"]["y"]) < TOL32
+    # DiffAugment() itself: draws on the device, capturable, differentiable twice; a replay makes fresh draws
+    aug = DA.DiffAugment()
+    xs = torch.randn(4, 3, 32, 32, device=dev)
+    aug(xs)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        xg = xs.clone().requires_grad_(True)
+        out = aug(xg)
+        (gx,) = torch.autograd.grad(out.square().sum(), xg, create_graph=True)
+        (ggx,) = torch.autograd.grad(gx.square().sum(), xg)
+    graph.replay()
+    torch.cuda.synchronize()
+    first = out.clone()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all() and torch.isfinite(ggx).all() and not torch.equal(first, out)
+    with pytest.raises(Exception):
+        DA.diff_augment(torch.randn(2, 8, 16, 16, device=dev), *[torch.rand(2, device=dev)] * 3, 0, 0, 0, 0)  # not an image batch

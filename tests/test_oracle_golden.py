@@ -306,3 +306,19 @@ def test_generators_v1(golden, name):
             assert float((projections(got) - ref).abs().max()) < 2e-4 * float(ref[1]), k
         else:
             assert rel_err(got, ref) < TOL2, (k, rel_err(got, ref))
+
+
+def test_diff_augment(golden):
+    """oracle.diff_augment (draws explicit) against the reference's DiffAugment()(x) with its draws recovered by re-seeding
+    (oracle/make_goldens.py: gold_diff_augment): image, gradient, gradient of the gradient's norm."""
+    for tag, g in golden("diff_augment").items():
+        x = g["x"].double().requires_grad_(True)
+        tx, ty = g["translate"]
+        oy, ox = g["cutout"]
+        y = O.diff_augment(x, g["brightness"].double(), g["saturation"].double(), g["contrast"].double(), tx, ty, oy, ox)
+        assert rel_err(y, g["y"]) < 1e-6, tag
+        loss = (y * g["wgt"].double()).sum() + y.square().mean()
+        assert abs(float(loss) - g["loss"]) <= 1e-5 * max(1.0, abs(g["loss"]))
+        (g1,) = torch.autograd.grad(loss, x, create_graph=True)
+        (g2,) = torch.autograd.grad(g1.square().sum(), x)
+        assert rel_err(g1, g["grad"]) < 1e-5 and rel_err(g2, g["grad2"]) < 1e-5, tag
