@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GAN_AMD_LIB") or os.path.join(_HERE, "libgan_amd.so")
 
 GAN_F32, GAN_BF16 = 0, 1
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 _SIGNATURES = {
     "gan_amd_version": (c_int, []),
@@ -66,6 +66,10 @@ _SIGNATURES = {
     "gan_space_to_depth": (c_int, [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),
     "gan_rgb_conv1x1_fwd": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int] + [c_int] * 5 + [c_float, c_void_p]),
     "gan_rgb_conv1x1_dgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
+    "gan_mapping_fwd": (c_int, [c_void_p] * 5 + [c_int, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_void_p]),
+    "gan_mapping_bwd_workspace": (c_int64, [c_int, c_int]),
+    "gan_mapping_bwd": (c_int, [c_void_p] * 6 + [c_int, c_void_p, c_void_p, c_int64, c_int, c_int, c_float, c_void_p]),
+    "gan_split_cols": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "gan_diffaug_workspace": (c_int64, [c_int]),
     "gan_diffaug": (c_int, [c_void_p] + [c_int64] * 4 + [c_void_p] * 3 + [c_int] * 5 + [c_void_p, c_int64, c_int, c_void_p]),
     "gan_rgb_conv1x1_wgrad_workspace": (c_int64, [c_int, c_int]),

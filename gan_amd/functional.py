@@ -987,6 +987,115 @@ class AffineActFn(Function):
 
 
 # ======================================================================================
+# the generator's mapping network and style split (gan_amd/csrc/mapping.hip)
+# ======================================================================================
+def _ptr_array(tensors):
+    import ctypes
+
+    return (ctypes.c_void_p * len(tensors))(*[None if t is None else t.data_ptr() for t in tensors])
+
+
+class MappingFn(Function):
+    """w = mapping_network(z): LayerNorm(128) then L x [Linear(128, 128), LeakyReLU(slope)] (stylegan2.py:70-72,93) in one
+    launch; backward in two.  Inputs: z, ln weight, ln bias, then W_0, b_0, ..., W_{L-1}, b_{L-1}.  No gradient for z
+    (callers whose z needs one, and backward passes that are themselves recorded, take the library path instead)."""
+
+    @staticmethod
+    def forward(ctx, z, ln_w, ln_b, slope, eps, *wb):
+        lib = _lib.load()
+        ws, bs = list(wb[0::2]), list(wb[1::2])
+        n, dim = z.shape
+        L = len(ws)
+        z = z.detach().contiguous()
+        acts = torch.empty((L + 1, n, dim), dtype=torch.float32, device=z.device)
+        stats = torch.empty((n, 2), dtype=torch.float32, device=z.device)
+        check(lib.gan_mapping_fwd(ptr(z), ptr(ln_w), ptr(ln_b), _ptr_array(ws), _ptr_array(bs), L, ptr(acts), ptr(stats), n, dim, float(slope),
+                                  float(eps), stream_of(z)), "gan_mapping_fwd")
+        ctx.save_for_backward(z, ln_w, acts, stats, *ws)
+        ctx.slope, ctx.has_bias = slope, [b is not None for b in bs]
+        return acts[L]
+
+    @staticmethod
+    def backward(ctx, g):
+        if torch.is_grad_enabled():
+            raise _lib.GanAmdError("MappingFn: this backward pass is being recorded (create_graph); use the module path (mapping_network(...))")
+        lib = _lib.load()
+        z, ln_w, acts, stats, *ws = ctx.saved_tensors
+        n, dim = z.shape
+        L = len(ws)
+        g = g.detach().to(torch.float32).contiguous()
+        grads = torch.empty((L * (dim * dim + dim) + 2 * dim,), dtype=torch.float32, device=z.device)
+        wsp_floats = lib.gan_mapping_bwd_workspace(n, L)
+        wsp = torch.empty((wsp_floats,), dtype=torch.float32, device=z.device)
+        check(lib.gan_mapping_bwd(ptr(g), ptr(acts), ptr(stats), ptr(z), ptr(ln_w), _ptr_array(ws), L, ptr(grads), ptr(wsp), wsp_floats, n, dim,
+                                  float(ctx.slope), stream_of(z)), "gan_mapping_bwd")
+        dW = grads[: L * dim * dim].view(L, dim, dim)
+        dB = grads[L * dim * dim : L * (dim * dim + dim)].view(L, dim)
+        tail = grads[L * (dim * dim + dim) :]
+        out = [None, tail[:dim] if ctx.needs_input_grad[1] else None, tail[dim:] if ctx.needs_input_grad[2] else None, None, None]
+        for l in range(L):
+            out.append(dW[l] if ctx.needs_input_grad[5 + 2 * l] else None)
+            out.append(dB[l] if ctx.has_bias[l] and ctx.needs_input_grad[6 + 2 * l] else None)
+        return tuple(out)
+
+
+def mapping_network(net: torch.nn.Sequential, z: Tensor) -> Tensor:
+    """`net(z)` for the reference's mapping network; the fused kernels when it is LayerNorm(128) + up to 8 x [Linear(128, 128),
+    LeakyReLU] in fp32 on the GPU, z needs no gradient and the pass is not under create_graph -- else the modules as they are."""
+    mods = list(net)
+    ok = (len(mods) >= 3 and len(mods) % 2 == 1 and isinstance(mods[0], torch.nn.LayerNorm) and z.is_cuda and z.dim() == 2 and z.shape[1] == 128
+          and tuple(mods[0].normalized_shape) == (128,) and not z.requires_grad and (len(mods) - 1) // 2 <= 8 and z.shape[0] > 0)
+    lins, slope = [], None
+    if ok:
+        for lin, act in zip(mods[1::2], mods[2::2]):
+            if not (isinstance(lin, torch.nn.Linear) and isinstance(act, torch.nn.LeakyReLU) and lin.in_features == 128 and lin.out_features == 128
+                    and lin.weight.dtype == torch.float32 and lin.weight.is_contiguous() and act.negative_slope > 0
+                    and (slope is None or slope == act.negative_slope)):
+                ok = False
+                break
+            slope = act.negative_slope
+            lins.append(lin)
+    if not ok:
+        return net(z)
+    ln = mods[0]
+    wb = []
+    for lin in lins:
+        wb += [lin.weight, lin.bias]
+    return MappingFn.apply(z.float(), ln.weight, ln.bias, slope, ln.eps, *wb)
+
+
+_SPLIT_OFFSETS: dict = {}
+
+
+class SplitColsFn(Function):
+    """(N, T) fp32 -> one contiguous (N, C_l) tensor per layer (views of one buffer), one launch; backward: one torch.cat."""
+
+    @staticmethod
+    def forward(ctx, x, sizes):
+        lib = _lib.load()
+        n, t = x.shape
+        key = (x.device, tuple(sizes))
+        off = _SPLIT_OFFSETS.get(key)
+        if off is None:
+            acc = [0]
+            for c in sizes:
+                acc.append(acc[-1] + c)
+            off = _SPLIT_OFFSETS[key] = (torch.tensor(acc, dtype=torch.int32, device=x.device), acc)
+        x = x.detach().to(torch.float32).contiguous()
+        out = torch.empty((n * t,), dtype=torch.float32, device=x.device)
+        check(lib.gan_split_cols(ptr(x), ptr(out), ptr(off[0]), len(sizes), n, t, 0, stream_of(x)), "gan_split_cols")
+        ctx.sizes = tuple(sizes)
+        return tuple(out[n * a : n * b].view(n, b - a) for a, b in zip(off[1][:-1], off[1][1:]))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        n = next(g.shape[0] for g in grads if g is not None)
+        dev = next(g.device for g in grads if g is not None)
+        full = [g if g is not None else torch.zeros((n, c), dtype=torch.float32, device=dev) for g, c in zip(grads, ctx.sizes)]
+        return torch.cat(full, dim=1), None
+
+
+# ======================================================================================
 # functional API
 # ======================================================================================
 def upfirdn2d(imgs: Tensor, kernel: Tensor, up: int, down: int, px1: int, px2: int, py1: int, py2: int) -> Tensor:

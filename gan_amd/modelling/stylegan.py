@@ -92,7 +92,7 @@ class StyleGanGenerator(nn.Module):
 
     def forward(self, z: Tensor) -> Tensor:
         with torch.autocast("cuda", enabled=False):  # (N, 128) x (128, 128) products: plain library GEMMs in fp32
-            w = self.mapping_network(z.float()) * 0.01
+            w = GF.mapping_network(self.mapping_network, z.float()) * 0.01
         dt = GF.act_dtype(z)
         x = self.learned_input.to(dt).expand(z.shape[0], -1, -1, -1)
         x = self.blocks[0](x, w)

@@ -287,13 +287,17 @@ class StyleGan2Generator(nn.Module):
             a_all = torch.cat([m.style_weight.weight for m in mods], 0)
             b_all = torch.cat([m.style_weight.bias for m in mods], 0)
             s_all = F.linear(w.float(), a_all, b_all) + 1
-            for m, s in zip(mods, torch.split(s_all, [m.in_channels for m in mods], dim=1)):
-                m._styles = s.contiguous()
+            if s_all.is_cuda:
+                parts = GF.SplitColsFn.apply(s_all, tuple(m.in_channels for m in mods))  # one launch, not a copy per layer
+            else:
+                parts = [s.contiguous() for s in torch.split(s_all, [m.in_channels for m in mods], dim=1)]
+            for m, s in zip(mods, parts):
+                m._styles = s
 
     def forward(self, z: Tensor) -> Tensor:
-        # mapping network: 8 x (128x128 Linear + LeakyReLU) on (N,128) -- plain library GEMMs (hipBLASLt)
-        with torch.autocast("cuda", enabled=False):  # (N,128) x (128,128) products: fp32 costs nothing and spares
-            w = self.mapping_network(z.float())       # a bf16 cast of every weight and bias per call
+        # mapping network: LayerNorm + 8 x (128x128 Linear + LeakyReLU) on (N,128), fp32 -- one launch (mapping.hip)
+        with torch.autocast("cuda", enabled=False):
+            w = GF.mapping_network(self.mapping_network, z.float())
         self._all_styles(w)
         dt = GF.act_dtype(z)
         x = self.learned_input.to(dt).expand(z.shape[0], -1, -1, -1)

@@ -259,6 +259,24 @@ int gan_rgb_conv1x1_wgrad(const void* x, int x_dtype, int64_t sn, int64_t sc, in
  *          2 = its adjoint y = A' x (the gradient of modes 0 and 1) -- closed under differentiation, as R1 needs.
  * Every draw is read on the device, so the call can be captured in a HIP graph (the reference's `.item()` cannot).
  * workspace: gan_diffaug_workspace(N) floats, caller-owned, contents undefined on entry and exit. */
+/* The generator's mapping network (stylegan2.py:70-72,93): LayerNorm(dim) then L x [Linear(dim, dim), LeakyReLU(slope)],
+ * dim = 128, L <= 8, fp32 -- one launch forward, two backward, instead of ~17 and ~50 library calls.
+ *   fwd : acts [L+1][N][dim]: acts[0] = LayerNorm(z), acts[l+1] = lrelu(acts[l] W_l' + B_l) (the network's output is
+ *         acts[L]); stats [N][2] = (mean, rstd) of LayerNorm.  W, B: host arrays of L device pointers (nn.Linear's
+ *         (out, in) weights and biases where they are; B or its entries may be null); ln_w / ln_b may be null.
+ *   bwd : from gout [N][dim] (the gradient at acts[L]) to `grads`, one flat fp32 buffer laid out
+ *         dW[L][dim][dim], dB[L][dim], dln_w[dim], dln_b[dim]; no gradient for z (a random draw in every caller).
+ *         workspace: gan_mapping_bwd_workspace(N, L) floats, caller-owned (per-workgroup partials, folded in a fixed
+ *         order: deterministic).
+ * gan_split_cols: [N][T] -> the concatenation of contiguous [N][C_l] blocks, block l at N * offsets[l] (offsets: nl + 1
+ * device ints, offsets[nl] = T); reverse = 1 is the inverse.  One launch instead of a copy per ModulatedConv2d style. */
+int gan_mapping_fwd(const float* z, const float* ln_w, const float* ln_b, const float* const* W, const float* const* B, int L, float* acts,
+                    float* stats, int N, int dim, float slope, float eps, gan_stream_t stream);
+int64_t gan_mapping_bwd_workspace(int N, int L);
+int gan_mapping_bwd(const float* gout, const float* acts, const float* stats, const float* z, const float* ln_w, const float* const* W, int L,
+                    float* grads, float* workspace, int64_t workspace_floats, int N, int dim, float slope, gan_stream_t stream);
+int gan_split_cols(const float* in, float* out, const int* offsets, int nl, int N, int T, int reverse, gan_stream_t stream);
+
 int64_t gan_diffaug_workspace(int N);
 int gan_diffaug(const void* in, int64_t sn, int64_t sc, int64_t sh, int64_t sw, void* out, const float* usk, const int* shift, int mode, int N,
                 int C, int H, int W, float* workspace, int64_t workspace_floats, int dtype, gan_stream_t stream);

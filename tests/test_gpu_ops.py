@@ -3,6 +3,8 @@
 Tolerances are BASELINE.json's: rel-err <= 1e-5 in fp32 and <= 1e-2 in bf16, forward and
 gradients (rel-err = ||a-b|| / ||b||); second-order quantities get 1e-4 in fp32.
 The oracle runs on the CPU (fp64 where cheap) on the same inputs."""
+import copy
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -1028,3 +1030,52 @@ def test_diff_augment_kernel(dev, golden, monkeypatch):
     assert torch.isfinite(out).all() and torch.isfinite(ggx).all() and not torch.equal(first, out)
     with pytest.raises(Exception):
         DA.diff_augment(torch.randn(2, 8, 16, 16, device=dev), *[torch.rand(2, device=dev)] * 3, 0, 0, 0, 0)  # not an image batch
+
+
+@pytest.mark.parametrize("n,depth", [(3, 8), (32, 8), (70, 5)])
+def test_mapping_network_kernels(dev, n, depth):
+    """gan_mapping_fwd / gan_mapping_bwd behind GF.mapping_network: LayerNorm(128) + depth x [Linear, LeakyReLU(0.2)]
+    (stylegan2.py:70-72) against the same modules in fp64: output and every parameter gradient; and gan_split_cols
+    (the per-layer styles out of one GEMM) both ways."""
+    import gan_amd.functional as GF
+    from torch import nn
+
+    torch.manual_seed(47)
+    net = nn.Sequential(nn.LayerNorm(128))
+    for _ in range(depth):
+        net.extend([nn.Linear(128, 128), nn.LeakyReLU(0.2)])
+    with torch.no_grad():
+        net[0].weight.uniform_(0.5, 1.5)
+        net[0].bias.normal_(0, 0.2)
+    ref_net = copy.deepcopy(net).double()
+    net = net.to(dev)
+    z = torch.randn(n, 128)
+    cot = torch.randn(n, 128)
+    ref = ref_net(z.double())
+    (ref * cot.double()).sum().backward()
+    got = GF.mapping_network(net, z.to(dev))
+    assert got.grad_fn is not None and type(got.grad_fn).__name__.startswith("MappingFn")
+    assert rel_err(got, ref) < TOL32
+    (got * cot.to(dev)).sum().backward()
+    for (name, p), q in zip(net.named_parameters(), ref_net.parameters()):
+        assert rel_err(p.grad, q.grad) < TOL32, (name, rel_err(p.grad, q.grad))
+    with torch.no_grad():
+        assert rel_err(GF.mapping_network(net, z.to(dev)), ref) < TOL32
+    # a z that needs a gradient takes the module path
+    zg = z.to(dev).requires_grad_(True)
+    out = GF.mapping_network(net, zg)
+    (gz,) = torch.autograd.grad((out * cot.to(dev)).sum(), zg)
+    zr = z.double().requires_grad_(True)
+    (gz_ref,) = torch.autograd.grad((ref_net(zr) * cot.double()).sum(), zr)
+    assert rel_err(gz, gz_ref) < 1e-4
+
+    sizes = (512, 16, 3, 64, 129)
+    x = torch.randn(n, sum(sizes), device=dev, requires_grad=True)
+    parts = GF.SplitColsFn.apply(x, sizes)
+    off = 0
+    for part, c in zip(parts, sizes):
+        assert part.is_contiguous() and torch.equal(part, x[:, off:off + c])
+        off += c
+    wts = [torch.randn_like(p_) for p_ in parts]
+    (gx,) = torch.autograd.grad(sum((p_ * w_).sum() for p_, w_ in zip(parts[:-1], wts[:-1])), x)  # the last part unused: a None gradient
+    assert torch.equal(gx, torch.cat(wts[:-1] + [torch.zeros_like(wts[-1])], dim=1))
