@@ -419,10 +419,11 @@ int gan_conv2d_fwd_wide_halo(const void* x, const void* wt, void* y, const float
     a.aux = fu.aux; a.resid = fu.resid; a.slope = slope; a.aux_slope = fu.aux_slope; a.gain = fu.gain;
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.up2 = up2; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout; a.Kpad = Kpad; a.pool = fu.pool;
     a.t8 = t8;
-    // 16-wide tilings with 128-channel tiles run as 4-wave workgroups of 8 x 16 pixels, two per CU: one's prologue and
-    // epilogue (a quarter of a wave's lifetime at Cin = 128) overlap the other's K loop.  The rest: 8 waves, 256 pixels.
+    // 16-wide tilings run as 4-wave workgroups of 8 x 16 pixels, two per CU: one's prologue and epilogue (a quarter of a
+    // wave's lifetime at Cin = 128) overlap the other's K loop (128 -> 128 @ 32x32: 120 -> 106 us; 128 -> 64 upsampled to
+    // 64x64: 232 -> 195 us).  The 8 x 8 tiling needs four images' halos at once: 8 waves, 256 pixels, one workgroup per CU.
     const int BN = Cout > 64 ? 128 : 64;
-    const int waves = (!t8 && BN == 128) ? 4 : 8;
+    const int waves = !t8 ? 4 : 8;
     const int TW = t8 ? 8 : 16, TH = t8 ? 8 : 2 * waves, imgs = t8 ? 4 : 1;
     a.tiles_x = Wo / TW; a.tiles_y = Ho / TH;
     a.P = (up2 ? TW / 2 : TW) + 2;   // halo row pitch and rows per image, in source pixels
@@ -454,10 +455,14 @@ int gan_conv2d_fwd_wide_halo(const void* x, const void* wt, void* y, const float
     const int64_t items = tiles * gn;
     const size_t lds = (size_t)2 * a.perh * waves * 1024 + (size_t)(waves == 8 ? 3 : 2) * BN * 128;
     const dim3 grid((unsigned)items);
-    if (waves == 4 && up2)
+    if (waves == 4 && BN == 128 && up2)
         hipLaunchKernelGGL((conv_wide_halo_k<128, 4, true>), grid, dim3(256), lds, st, a);
-    else if (waves == 4)
+    else if (waves == 4 && BN == 128)
         hipLaunchKernelGGL((conv_wide_halo_k<128, 4, false>), grid, dim3(256), lds, st, a);
+    else if (waves == 4 && up2)
+        hipLaunchKernelGGL((conv_wide_halo_k<64, 4, true>), grid, dim3(256), lds, st, a);
+    else if (waves == 4)
+        hipLaunchKernelGGL((conv_wide_halo_k<64, 4, false>), grid, dim3(256), lds, st, a);
     else if (BN == 128 && up2)
         hipLaunchKernelGGL((conv_wide_halo_k<128, 8, true>), grid, dim3(512), lds, st, a);
     else if (BN == 128)

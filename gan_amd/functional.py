@@ -454,7 +454,7 @@ def _halo_kernel_shape(x: Tensor, cout: int, ho: int, wo: int, kh: int, kw: int,
     if not t16 and (ho % 8 or wo % 8):
         return False
     bn = 128 if cout > 64 else 64
-    waves = 4 if (t16 and bn == 128) else 8
+    waves = 4 if t16 else 8
     tiles = -(-n // (1 if t16 else 4)) * (wo // (16 if t16 else 8)) * (ho // (2 * waves if t16 else 8))
     dev = x.device.index or 0
     if dev not in _CUS:

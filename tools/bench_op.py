@@ -1,4 +1,4 @@
-"""Micro-driver for one library op (profiling aid): python tools/bench_op.py wgrad N Cin H W Cout k [iters]"""
+"""Micro-driver for one library op (profiling aid): python tools/bench_op.py wgrad|fwd|fwd_up2|fwd_pool N Cin H W Cout k [iters]"""
 import sys, torch
 import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -16,6 +16,10 @@ def run():
         return GF.raw_conv2d_wgrad(x, gy, k, k, pad, pad)
     if op == 'fwd':
         return GF.raw_conv2d(x, wgt, pad, pad)
+    if op == 'fwd_up2':
+        return GF.raw_conv2d(x, wgt, pad, pad, up2=True)
+    if op == 'fwd_pool':
+        return GF.raw_conv2d(x, wgt, pad, pad, pool=True)
     raise SystemExit(op)
 for _ in range(3): run()
 torch.cuda.synchronize()
@@ -24,4 +28,5 @@ e0.record()
 for _ in range(iters): run()
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / iters
-print(f"{op} {n}x{cin}x{h}x{w}->{cout} k{k}: {ms*1e3:.1f} us  {2.0*n*h*w*cout*cin*k*k/ms/1e9:.1f} TFLOP/s")
+hw = 4 * h * w if op == 'fwd_up2' else h * w
+print(f"{op} {n}x{cin}x{h}x{w}->{cout} k{k}: {ms*1e3:.1f} us  {2.0*n*hw*cout*cin*k*k/ms/1e9:.1f} TFLOP/s")
