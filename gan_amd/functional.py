@@ -339,6 +339,17 @@ def _pad_channels(x: Tensor, mult: int, dtype: Optional[torch.dtype] = None) -> 
     return as_cl(F.pad(x, (0, 0, 0, 0, 0, rem)))
 
 
+def _packed_rows(rows: int, kpad: int, dtype: torch.dtype, device) -> Tensor:
+    """Storage of a packed weight image.  Wide odd row counts (the 513 rows of the input-gradient image of the layer
+    behind MinibatchStdDev, progressive_gan.py:71) get zero rows up to a multiple of 8, so that raw_conv2d can run the
+    layer with a padded output-channel count on the LDS-DMA kernels instead of the register-staged fallback."""
+    rows_p = rows + ((-rows) % 8) if rows > 64 else rows
+    out = torch.empty((rows_p, kpad), dtype=dtype, device=device)
+    if rows_p != rows:
+        out[rows:].zero_()
+    return out
+
+
 def _pack_weight(weight: Tensor, dtype: torch.dtype, cin_mult: int, transposed: bool) -> Tuple[Tensor, int, int]:
     cout, cin, kh, kw = weight.shape
     rows, cols = (cin, cout) if transposed else (cout, cin)
@@ -348,7 +359,7 @@ def _pack_weight(weight: Tensor, dtype: torch.dtype, cin_mult: int, transposed: 
     if weight.dtype not in (torch.float32, torch.bfloat16):
         weight = weight.float()
     weight = weight.contiguous()
-    out = torch.empty((rows, kpad), dtype=dtype, device=weight.device)
+    out = _packed_rows(rows, kpad, dtype, weight.device)
     check(
         _lib.load().gan_pack_weight(ptr(weight), dtype_code(weight), ptr(out), dtype_code(out), cout, cin, kh, kw, cols_p, kpad,
                                     int(transposed), stream_of(weight)),
@@ -371,8 +382,8 @@ def _pack_weight_pair(weight: Tensor, dtype: torch.dtype, mult_f: int, mult_t: i
     kf, kt = kh * kw * cp_f, kh * kw * cp_t
     kpad_f, kpad_t = kf + ((-kf) % 32), kt + ((-kt) % 32)
     weight = weight.contiguous()
-    out_f = torch.empty((cout, kpad_f), dtype=dtype, device=weight.device)
-    out_t = torch.empty((cin, kpad_t), dtype=dtype, device=weight.device)
+    out_f = _packed_rows(cout, kpad_f, dtype, weight.device)
+    out_t = _packed_rows(cin, kpad_t, dtype, weight.device)
     check(
         _lib.load().gan_pack_weight_pair(ptr(weight), dtype_code(weight), ptr(out_f), cp_f, kpad_f, ptr(out_t), cp_t, kpad_t,
                                          dtype_code(out_f), cout, cin, kh, kw, stream_of(weight)),
@@ -542,6 +553,13 @@ def raw_conv2d(
         if tuple(resid.shape) != (n, cout, hy, wy):
             raise _lib.GanAmdError(f"conv2d: resid shape {tuple(resid.shape)} != output shape {(n, cout, hy, wy)}")
         resid = as_cl(resid.detach().to(x.dtype))
+    # an odd, wide output-channel count (513: the input gradient of the layer behind MinibatchStdDev) with no per-channel
+    # side inputs: computed with the count rounded up to 8 (the packed image has zero rows there) on the wide kernels --
+    # 95 -> ~30 us per call at any batch size -- and handed back as a channel slice
+    cout_real = cout
+    if (x.dtype == torch.bfloat16 and cout > 64 and cout % 8 and wt.shape[0] >= cout + (-cout) % 8 and out_scale32 is None and bias32 is None
+            and ns32 is None and noise is None and aux is None and resid is None):
+        cout = cout + (-cout) % 8
     y = _empty_like_cl(x, (n, cout, hy, wy))
     if _thin_kernel_shape(x, cin_p, cout, ho, wo, kh, kw, py, px):
         # HBM-bound; one family per device kernel instantiation conv_thin_k<CIN, COUT, KS, RPW, MODE, VEC>
@@ -558,17 +576,17 @@ def raw_conv2d(
         family = "conv2d_fwd"
     check(
         _run(
-            family, 2.0 * n * ho * wo * cout * cin * kh * kw, _nbytes(x, y, wt, noise, aux, resid),
+            family, 2.0 * n * ho * wo * cout_real * cin * kh * kw, _nbytes(x, y, wt, noise, aux, resid),
             lambda: lib.gan_conv2d_fwd(
                 ptr(x), ptr(wt), ptr(y), ptr(in_scale), ptr(out_scale32), ptr(bias32), ptr(noise), ptr(ns32), float(slope),
                 n, h, w, cin_p, int(up2), ho, wo, cout, kh, kw, py, px, kpad,
                 float(in_slope), int(pool), ptr(aux), float(aux_slope), float(gain), ptr(resid), dtype_code(x), stream_of(x),
             ),
-            (n, cin, ho, wo, cout, kh, int(up2), int(pool)),
+            (n, cin, ho, wo, cout_real, kh, int(up2), int(pool)),
         ),
         "gan_conv2d_fwd",
     )
-    return y
+    return y if cout == cout_real else y[:, :cout_real]
 
 
 def raw_conv2d_dgrad(

@@ -1,9 +1,10 @@
-"""Profiling aid: one event-bracketed iteration, launches grouped by (family, shape tag).  python tools/by_shape.py [global_batch] [family substring]"""
+"""Profiling aid: one event-bracketed iteration, launches grouped by (family, shape tag).
+python tools/by_shape.py [global_batch] [family substring] [extra bench.py flags, e.g. --recipe dcgan --img_size 64]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 batch = sys.argv[1] if len(sys.argv) > 1 else '256'
 pat = sys.argv[2] if len(sys.argv) > 2 else ''
-sys.argv = ['bench.py', '--no_graph', '--global_batch', batch]
+sys.argv = ['bench.py', '--no_graph', '--global_batch', batch] + sys.argv[3:]
 import torch
 import bench
 import gan_amd.functional as GF
