@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GAN_AMD_LIB") or os.path.join(_HERE, "libgan_amd.so")
 
 GAN_F32, GAN_BF16 = 0, 1
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 _SIGNATURES = {
     "gan_amd_version": (c_int, []),
@@ -38,6 +38,11 @@ _SIGNATURES = {
     "gan_conv2d_fwd": (
         c_int,
         [c_void_p] * 8 + [c_float] + [c_int] * 13 + [c_float, c_int, c_void_p, c_float, c_float, c_void_p] + [c_int, c_void_p],
+    ),
+    "gan_conv2d_fwd_workspace": (c_int64, [c_int] * 10),
+    "gan_conv2d_fwd_ws": (
+        c_int,
+        [c_void_p] * 8 + [c_float] + [c_int] * 13 + [c_float, c_int, c_void_p, c_float, c_float, c_void_p] + [c_void_p, c_int64, c_int, c_void_p],
     ),
     "gan_conv2d_wgrad_workspace": (c_int64, [c_int] * 13),
     "gan_conv2d_wgrad": (c_int, [c_void_p] * 3 + [c_int, c_int, c_void_p] + [c_int] * 12 + [c_void_p, c_int64, c_float, c_int, c_float, c_int, c_int, c_void_p]),

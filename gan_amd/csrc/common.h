@@ -132,6 +132,8 @@ struct ConvFuse {
     float aux_slope;
     float gain;
     const void* resid;  // nullptr, or a tensor shaped like y added to the result last (a second gradient path)
+    float* ws;          // optional caller workspace (gan_conv2d_fwd_ws): lets small-grid wide layers split K
+    int64_t ws_floats;
 };
 
 // conv_thin.hip: direct convolution for thin layers (bf16).  1 = served, 0 = shape not eligible, < 0 = error.
@@ -145,6 +147,8 @@ int gan_conv2d_fwd_wide(const void* x, const void* wt, void* y, const float* out
                         const void* noise, const float* noise_scale, float slope, int N, int H, int W, int Cin, int up2,
                         int Ho, int Wo, int Cout, int kh, int kw, int py, int px, int Kpad, const ConvFuse& fu,
                         hipStream_t st);
+
+int64_t gan_conv2d_fwd_wide_workspace(int N, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int Kpad);
 
 // conv_wide_halo.hip: the 3x3 case of the above with the input halo resident in LDS across the nine taps.
 int gan_conv2d_fwd_wide_halo(const void* x, const void* wt, void* y, const float* out_scale, const float* bias,

@@ -400,11 +400,11 @@ __global__ void __launch_bounds__(256) conv_full_k(const T* __restrict__ x, cons
     }
 }
 
-extern "C" int gan_conv2d_fwd(const void* x, const void* wt, void* y, const float* in_scale, const float* out_scale,
-                              const float* bias, const void* noise, const float* noise_scale, float slope, int N,
-                              int H, int W, int Cin, int up2, int Ho, int Wo, int Cout, int kh, int kw, int py, int px,
-                              int Kpad, float in_slope, int pool, const void* aux, float aux_slope, float gain, const void* resid,
-                              int dtype, gan_stream_t stream) {
+static int conv2d_fwd_impl(const void* x, const void* wt, void* y, const float* in_scale, const float* out_scale,
+                           const float* bias, const void* noise, const float* noise_scale, float slope, int N,
+                           int H, int W, int Cin, int up2, int Ho, int Wo, int Cout, int kh, int kw, int py, int px,
+                           int Kpad, float in_slope, int pool, const void* aux, float aux_slope, float gain, const void* resid,
+                           float* workspace, int64_t workspace_floats, int dtype, gan_stream_t stream) {
     GAN_CHECK_ARG(N == 0 || (x && wt && y), "conv2d_fwd: null pointer");
     GAN_CHECK_ARG(dtype == GAN_F32 || dtype == GAN_BF16, "conv2d_fwd: bad dtype %d", dtype);
     GAN_CHECK_ARG(N >= 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Ho > 0 && Wo > 0, "conv2d_fwd: bad shape");
@@ -423,6 +423,7 @@ extern "C" int gan_conv2d_fwd(const void* x, const void* wt, void* y, const floa
     if (N == 0) return GAN_OK;
     ConvArgs a;
     a.fu.in_slope = in_slope; a.fu.pool = pool; a.fu.aux = aux; a.fu.aux_slope = aux_slope; a.fu.gain = gain; a.fu.resid = resid;
+    a.fu.ws = workspace; a.fu.ws_floats = workspace ? workspace_floats : 0;
     a.x = x; a.wt = wt; a.y = y;
     a.in_scale = in_scale; a.out_scale = out_scale; a.bias = bias;
     a.noise = noise; a.noise_scale = noise_scale; a.slope = slope;
@@ -454,4 +455,28 @@ extern "C" int gan_conv2d_fwd(const void* x, const void* wt, void* y, const floa
         if (wide != 0) return wide < 0 ? wide : GAN_OK;
     }
     return launch<bf16>(a, st);
+}
+
+extern "C" int gan_conv2d_fwd(const void* x, const void* wt, void* y, const float* in_scale, const float* out_scale,
+                              const float* bias, const void* noise, const float* noise_scale, float slope, int N,
+                              int H, int W, int Cin, int up2, int Ho, int Wo, int Cout, int kh, int kw, int py, int px,
+                              int Kpad, float in_slope, int pool, const void* aux, float aux_slope, float gain, const void* resid,
+                              int dtype, gan_stream_t stream) {
+    return conv2d_fwd_impl(x, wt, y, in_scale, out_scale, bias, noise, noise_scale, slope, N, H, W, Cin, up2, Ho, Wo, Cout, kh, kw, py, px, Kpad,
+                           in_slope, pool, aux, aux_slope, gain, resid, nullptr, 0, dtype, stream);
+}
+
+// ---- the same call with an optional caller workspace (include/gan_amd.h: gan_conv2d_fwd_ws) -----------------------------
+extern "C" int64_t gan_conv2d_fwd_workspace(int N, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int Kpad, int has_in_scale, int dtype) {
+    if (dtype != GAN_BF16 || has_in_scale || N <= 0) return 0;
+    return gan_conv2d_fwd_wide_workspace(N, Cin, Ho, Wo, Cout, kh, kw, Kpad);
+}
+
+extern "C" int gan_conv2d_fwd_ws(const void* x, const void* wt, void* y, const float* in_scale, const float* out_scale,
+                                 const float* bias, const void* noise, const float* noise_scale, float slope, int N,
+                                 int H, int W, int Cin, int up2, int Ho, int Wo, int Cout, int kh, int kw, int py, int px,
+                                 int Kpad, float in_slope, int pool, const void* aux, float aux_slope, float gain, const void* resid,
+                                 float* workspace, int64_t workspace_floats, int dtype, gan_stream_t stream) {
+    return conv2d_fwd_impl(x, wt, y, in_scale, out_scale, bias, noise, noise_scale, slope, N, H, W, Cin, up2, Ho, Wo, Cout, kh, kw, py, px, Kpad,
+                           in_slope, pool, aux, aux_slope, gain, resid, workspace, workspace_floats, dtype, stream);
 }

@@ -43,6 +43,8 @@ struct WideArgs {
     int N, H, W, Cin, Hl, Wl, up2, Ho, Wo, Cout, kw, py, px, Kpad, ksteps, pool;
     int M;
     unsigned x_bytes, w_bytes, y_bytes;
+    float* ws;        // split-K: fp32 partial tiles [ksplit][M][Cout], folded (with every output stage) by wide_splitk_fold_k
+    int ksplit, spk;  // K splits (blockIdx.z) and steps per split; ksplit == 1: the kernel finishes the tile itself
 };
 
 // buffer offsets of this lane's four pixel rows for tap (dy, dx): recomputed once per tap, not per K step
@@ -152,9 +154,18 @@ __global__ void __launch_bounds__(256, NST == 2 ? 2 : 1) conv_wide_k(const WideA
     // Per-lane source offsets change only when the K loop moves to the next tap; the channel block inside a tap
     // (and the k offset of the weight rows) is wave-uniform and rides in the instruction's scalar offset, so a
     // K step costs no address VALU at all.  (PMC before: 144 VALU instructions per step against 32 MFMAs.)
+    // this workgroup's K range (split-K over blockIdx.z: small grids, where a tile's serial chain of steps is the time)
+    const int s_begin = blockIdx.z * p.spk;
+    const int nsteps = (p.ksteps - s_begin) < p.spk ? (p.ksteps - s_begin) : p.spk;
     WideCursor cur;
-    cur.tap = cur.cb = cur.dy = cur.dx = 0;
-    wide_set_tap(cur.va, a_n, a_yx, 0, 0, csrc, p);
+    {
+        const int k0 = s_begin * 64;
+        cur.tap = k0 / p.Cin;
+        cur.cb = k0 - cur.tap * p.Cin;
+        cur.dy = cur.tap / p.kw;
+        cur.dx = cur.tap - cur.dy * p.kw;
+    }
+    wide_set_tap(cur.va, a_n, a_yx, cur.dy, cur.dx, csrc, p);
 
     f32x4 acc[FC][FP];
 #pragma unroll
@@ -170,12 +181,12 @@ __global__ void __launch_bounds__(256, NST == 2 ? 2 : 1) conv_wide_k(const WideA
 
 #pragma unroll
     for (int i = 0; i < NST - 1; ++i)
-        if (i < p.ksteps) wide_issue<BN, NST>(cur, lds, i, wave, rx, rw, b_off, a_n, a_yx, csrc, p);
+        if (i < nsteps) wide_issue<BN, NST>(cur, lds, i, wave, rx, rw, b_off, a_n, a_yx, csrc, p);
 
-    for (int s = 0; s < p.ksteps; ++s) {
+    for (int s = 0; s < nsteps; ++s) {
         // this wave's share of step s has landed: all but the (NST - 2) younger steps' DMAs are done (in the
         // tail fewer are in flight, so wait for everything)
-        if (NST > 2 && s + NST - 2 < p.ksteps) {
+        if (NST > 2 && s + NST - 2 < nsteps) {
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * PER) : "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -185,7 +196,7 @@ __global__ void __launch_bounds__(256, NST == 2 ? 2 : 1) conv_wide_k(const WideA
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         const int buf = s % NST;
-        if (s + NST - 1 < p.ksteps) wide_issue<BN, NST>(cur, lds, (s + NST - 1) % NST, wave, rx, rw, b_off, a_n, a_yx, csrc, p);
+        if (s + NST - 1 < nsteps) wide_issue<BN, NST>(cur, lds, (s + NST - 1) % NST, wave, rx, rw, b_off, a_n, a_yx, csrc, p);
         const char* const A = lds + buf * STAGE;
         const char* const B = A + A_BYTES;
 #pragma unroll
@@ -203,6 +214,20 @@ __global__ void __launch_bounds__(256, NST == 2 ? 2 : 1) conv_wide_k(const WideA
         }
     }
 
+    // ---- split-K: the raw fp32 partial tile goes to the workspace; wide_splitk_fold_k applies the output stages
+    if (p.ksplit > 1) {
+        float* __restrict__ part = p.ws + (int64_t)blockIdx.z * p.M * p.Cout;
+#pragma unroll
+        for (int f = 0; f < FP; ++f) {
+            const int m = bm0 + wm * 64 + f * 16 + frow;
+#pragma unroll
+            for (int i = 0; i < FC; ++i) {
+                const int co = bn0 + wn * (BN / 2) + i * 16 + fq * 4;
+                if (m < p.M && co < p.Cout) *reinterpret_cast<f32x4*>(part + (int64_t)m * p.Cout + co) = acc[i][f];
+            }
+        }
+        return;
+    }
     // ---- epilogue: lane holds channels co0..co0+3 (co0 = bn0 + wn*BN/2 + 16*i + 4*fq) of pixel row f*16 + frow
     const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t raux = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.aux), 0, p.aux ? p.y_bytes : 0u, 0x00020000);
@@ -272,7 +297,69 @@ __global__ void __launch_bounds__(256, NST == 2 ? 2 : 1) conv_wide_k(const WideA
     }
 }
 
+// Split-K fold: y[opix][co..co+3] = stages( sum_z ws[z][m][co..co+3] ), the output stages of conv_wide_k's epilogue on the
+// folded tile.  One thread per (output pixel, 4 channels); with pooling the pixel's four GEMM rows 4q .. 4q+3 are summed too.
+__global__ void __launch_bounds__(256) wide_splitk_fold_k(const WideArgs p) {
+    const int cq = p.Cout >> 2;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t npix = p.pool ? p.M >> 2 : p.M;
+    if (idx >= npix * cq) return;
+    const int opix = (int)(idx / cq), co = (int)(idx - (int64_t)opix * cq) * 4;
+    const int rows = p.pool ? 4 : 1;
+    const int64_t m0 = p.pool ? (int64_t)opix * 4 : opix;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    for (int z = 0; z < p.ksplit; ++z)
+        for (int r = 0; r < rows; ++r) a += *reinterpret_cast<const f32x4*>(p.ws + ((int64_t)z * p.M + m0 + r) * p.Cout + co);
+    const float gain = p.pool ? 0.25f * p.gain : p.gain;
+    const int out_per_img = p.pool ? (p.Ho * p.Wo) >> 2 : p.Ho * p.Wo;
+    const int n = opix / out_per_img;
+    float4 d4 = make_float4(1.f, 1.f, 1.f, 1.f), b4 = make_float4(0.f, 0.f, 0.f, 0.f), s4 = b4;
+    if (p.out_scale) d4 = *reinterpret_cast<const float4*>(p.out_scale + (int64_t)n * p.Cout + co);
+    if (p.bias) b4 = *reinterpret_cast<const float4*>(p.bias + co);
+    float nz = 0.f;
+    if (p.noise) {
+        nz = (float)reinterpret_cast<const bf16*>(p.noise)[opix];
+        s4 = *reinterpret_cast<const float4*>(p.noise_scale + co);
+    }
+    float v[4] = {fmaf(nz, s4.x, fmaf(a[0] * gain, d4.x, b4.x)), fmaf(nz, s4.y, fmaf(a[1] * gain, d4.y, b4.y)),
+                  fmaf(nz, s4.z, fmaf(a[2] * gain, d4.z, b4.z)), fmaf(nz, s4.w, fmaf(a[3] * gain, d4.w, b4.w))};
+    const int64_t o = (int64_t)opix * p.Cout + co;
+    bf16x4 out;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float u = lrelu_f(v[r], p.slope);
+        if (p.aux) u *= lrelu_mask((float)reinterpret_cast<const bf16*>(p.aux)[o + r], p.aux_slope);
+        if (p.resid) u += (float)reinterpret_cast<const bf16*>(p.resid)[o + r];
+        out[r] = (bf16)u;
+    }
+    *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(p.y) + o) = out;
+}
+
+// K splits for a grid of `wgs` 128 x 64 tiles with `ksteps` steps each: where the chip is mostly idle (fewer tiles than
+// half its CUs) and the chain is long, never more splits than leave 8 steps each; two for grids up to the CU count on
+// the 512-channel layers (64 x 512 x 8 x 8: 47 -> 44 us host-launched, batch 64: 20.5 -> 19.8 ms per iteration)
+int wide_ksplit(int64_t wgs, int ksteps) {
+    if (wgs > 256 || ksteps < 16) return 1;
+    if (wgs > 128) return ksteps >= 48 ? 2 : 1;  // two-stage variant, two workgroups per CU (see the launch); 36 steps: the fold costs more
+    int s = (int)(256 / wgs);
+    if (s > 8) s = 8;
+    if (s > ksteps / 8) s = ksteps / 8;
+    return s < 2 ? 1 : s;
+}
+
 }  // namespace
+
+// floats of workspace with which gan_conv2d_fwd_wide splits K for this shape (0: it does not)
+int64_t gan_conv2d_fwd_wide_workspace(int N, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int Kpad) {
+    if (Cin % 64 != 0 || Kpad != kh * kw * Cin || (Cout & 3)) return 0;
+    const int64_t M = (int64_t)N * Ho * Wo;
+    if (M < 128 || M >= (1LL << 31) - 256) return 0;
+    const int64_t gm = (M + 127) / 128, gn = (Cout + 127) / 128, gn64 = (Cout + 63) / 64;
+    static const int thr = getenv("GAN_AMD_WIDE_THR") ? atoi(getenv("GAN_AMD_WIDE_THR")) : 256;
+    if ((Cout > 64 && gm * gn >= thr) || gm * gn64 >= 2 * thr) return 0;
+    const int S = wide_ksplit(gm * gn64, Kpad / 64);
+    return S > 1 ? (int64_t)S * M * Cout : 0;
+}
 
 // 1 = served, 0 = shape not eligible, < 0 = error.  Never takes in_scale / in_slope (see the header comment).
 int gan_conv2d_fwd_wide(const void* x, const void* wt, void* y, const float* out_scale, const float* bias,
@@ -298,6 +385,7 @@ int gan_conv2d_fwd_wide(const void* x, const void* wt, void* y, const float* out
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Hl = up2 ? 2 * H : H; a.Wl = up2 ? 2 * W : W; a.up2 = up2;
     a.Ho = Ho; a.Wo = Wo; a.Cout = Cout; a.kw = kw; a.py = py; a.px = px; a.Kpad = Kpad; a.ksteps = Kpad / 64;
     a.pool = fu.pool; a.M = (int)M;
+    a.ws = nullptr; a.ksplit = 1; a.spk = a.ksteps;
     a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb; a.y_bytes = (unsigned)yb;
     const unsigned gm = (unsigned)((M + 127) / 128);
     const unsigned gn = (unsigned)((Cout + 127) / 128), gn64 = (unsigned)((Cout + 63) / 64);
@@ -310,7 +398,21 @@ int gan_conv2d_fwd_wide(const void* x, const void* wt, void* y, const float* out
     } else if ((int64_t)gm * gn64 >= 2 * thr) {
         hipLaunchKernelGGL((conv_wide_k<64, 2>), dim3(gm, gn64), dim3(256), 2 * (128 + 64) * 128, st, a);
     } else {
-        hipLaunchKernelGGL((conv_wide_k<64, 4>), dim3(gm, gn64), dim3(256), 4 * (128 + 64) * 128, st, a);
+        // small grid: with a workspace, split K so the chip fills and a tile's chain of steps shortens (72 steps of a
+        // 512-channel 3x3 layer are ~42 us whatever the batch), then fold the partial tiles with the output stages
+        const int S = wide_ksplit((int64_t)gm * gn64, a.ksteps);
+        if (S > 1 && fu.ws && fu.ws_floats >= (int64_t)S * M * Cout && (((uintptr_t)fu.ws) & 15) == 0) {
+            a.ws = fu.ws; a.ksplit = S; a.spk = (a.ksteps + S - 1) / S;
+            while ((a.ksplit - 1) * a.spk >= a.ksteps) --a.ksplit;  // no empty split
+        }
+        if (a.ksplit > 1 && (int64_t)gm * gn64 > 128)  // 2 x (129..256) workgroups: they only run at once with the 48 KB two-stage ring
+            hipLaunchKernelGGL((conv_wide_k<64, 2>), dim3(gm, gn64, (unsigned)a.ksplit), dim3(256), 2 * (128 + 64) * 128, st, a);
+        else
+            hipLaunchKernelGGL((conv_wide_k<64, 4>), dim3(gm, gn64, (unsigned)a.ksplit), dim3(256), 4 * (128 + 64) * 128, st, a);
+        if (a.ksplit > 1) {
+            const int64_t quads = (fu.pool ? M / 4 : M) * (Cout / 4);
+            hipLaunchKernelGGL(wide_splitk_fold_k, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, st, a);
+        }
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

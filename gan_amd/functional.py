@@ -561,6 +561,9 @@ def raw_conv2d(
             and ns32 is None and noise is None and aux is None and resid is None):
         cout = cout + (-cout) % 8
     y = _empty_like_cl(x, (n, cout, hy, wy))
+    # small-grid wide layers split K through a workspace (0 floats: this shape does not)
+    ws_floats = lib.gan_conv2d_fwd_workspace(n, cin_p, ho, wo, cout, kh, kw, kpad, int(in_scale is not None), dtype_code(x))
+    ws = torch.empty((ws_floats,), dtype=torch.float32, device=x.device) if ws_floats > 0 else None
     if _thin_kernel_shape(x, cin_p, cout, ho, wo, kh, kw, py, px):
         # HBM-bound; one family per device kernel instantiation conv_thin_k<CIN, COUT, KS, RPW, MODE, VEC>
         mode = "G" if (in_scale is not None or out_scale is not None or noise is not None) else ("DP" if pool else ("DA" if aux is not None else "D"))
@@ -577,10 +580,10 @@ def raw_conv2d(
     check(
         _run(
             family, 2.0 * n * ho * wo * cout_real * cin * kh * kw, _nbytes(x, y, wt, noise, aux, resid),
-            lambda: lib.gan_conv2d_fwd(
+            lambda: lib.gan_conv2d_fwd_ws(
                 ptr(x), ptr(wt), ptr(y), ptr(in_scale), ptr(out_scale32), ptr(bias32), ptr(noise), ptr(ns32), float(slope),
                 n, h, w, cin_p, int(up2), ho, wo, cout, kh, kw, py, px, kpad,
-                float(in_slope), int(pool), ptr(aux), float(aux_slope), float(gain), ptr(resid), dtype_code(x), stream_of(x),
+                float(in_slope), int(pool), ptr(aux), float(aux_slope), float(gain), ptr(resid), ptr(ws), ws_floats, dtype_code(x), stream_of(x),
             ),
             (n, cin, ho, wo, cout_real, kh, int(up2), int(pool)),
         ),

@@ -144,6 +144,18 @@ int gan_conv2d_fwd(const void* x, const void* wt, void* y, const float* in_scale
                    float in_slope, int pool, const void* aux, float aux_slope, float gain, const void* resid, int dtype,
                    gan_stream_t stream);
 
+/* gan_conv2d_fwd with an optional caller workspace.  A wide layer on a small grid (512 channels on 4x4 / 8x8 maps at a
+ * per-GPU batch of 32..64: fewer 128 x 64 tiles than half the chip's CUs) is a serial chain of K steps per tile -- 72 for a
+ * 512-channel 3x3 layer, ~42 us whatever the batch.  With gan_conv2d_fwd_workspace(...) floats of workspace (0: the shape does
+ * not split) the kernel splits K over up to 8 workgroups per tile, writes fp32 partial tiles there and a second kernel folds
+ * them in a fixed order and applies every output stage.  Same result up to fp32 summation order; workspace NULL or too
+ * small = gan_conv2d_fwd.  Contents of the workspace are undefined on entry and exit. */
+int64_t gan_conv2d_fwd_workspace(int N, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int Kpad, int has_in_scale, int dtype);
+int gan_conv2d_fwd_ws(const void* x, const void* wt, void* y, const float* in_scale, const float* out_scale, const float* bias,
+                      const void* noise, const float* noise_scale, float slope, int N, int H, int W, int Cin, int up2, int Ho, int Wo,
+                      int Cout, int kh, int kw, int py, int px, int Kpad, float in_slope, int pool, const void* aux, float aux_slope,
+                      float gain, const void* resid, float* workspace, int64_t workspace_floats, int dtype, gan_stream_t stream);
+
 /* Weight gradient (autograd of the convolutions above; torch.nn.grad.conv2d_weight in the reference's autograd):
  * dw[co][ci][ky][kx] = gain * sum_{n,oy,ox} gy[n,oy,ox,co] * X[n,oy+ky-py,ox+kx-px,ci] * in_scale[n,ci]
  * dw: fp32 (Cout_out, Cin_out, kh, kw) contiguous -- the parameter's own layout; every element is written

@@ -564,6 +564,58 @@ HALO_CASES = [
 ]
 
 
+@pytest.mark.parametrize("case", [
+    # N, Cin, H, W, Cout, up2, pool   (small grids: conv_wide_k splits K through the workspace of gan_conv2d_fwd_ws)
+    (8, 512, 4, 4, 512, False, False),   # 1 x 8 tiles: 8 splits of 9 steps
+    (32, 512, 8, 8, 512, False, True),   # 16 x 8 tiles: 2 splits, pooled fold (four GEMM rows per output pixel)
+    (32, 256, 4, 4, 128, True, False),   # nearest-2x, 36 steps
+    (64, 512, 8, 8, 512, False, False),  # 32 x 8 = 256 tiles: 2 splits on the two-stage variant
+    (5, 576, 4, 4, 72, False, False),    # ragged M (80 rows... below 128: the register-staged kernel) -- no split, same result
+    (9, 320, 4, 4, 200, False, False),   # 45 steps, 8 splits of 6 with a short last one; Cout tail
+])
+def test_conv2d_wide_splitk(dev, case):
+    """Split-K of the small-grid wide convolution: every output stage applied by the fold kernel, against fp64 and against
+    the unsplit kernel (gan_conv2d_fwd, no workspace) on the same inputs."""
+    import gan_amd.functional as GF
+    from gan_amd import _lib
+
+    n, cin, h, w, cout, up2, pool = case
+    torch.manual_seed(53)
+    lib = _lib.load()
+    x = torch.randn(n, cin, h, w).bfloat16().to(dev)
+    wgt = (torch.randn(cout, cin, 3, 3) / (cin * 9) ** 0.5).bfloat16().float().to(dev)
+    d = (torch.rand(n, cout) + 0.5).to(dev)
+    b = torch.randn(cout).to(dev)
+    ns = torch.randn(cout).to(dev)
+    ho, wo = (2 * h, 2 * w) if up2 else (h, w)
+    hy, wy = (ho // 2, wo // 2) if pool else (ho, wo)
+    noise = torch.randn(n, 1, hy, wy).bfloat16().to(dev)
+    aux = torch.randn(n, cout, hy, wy).bfloat16().to(dev)
+    res = torch.randn(n, cout, hy, wy).bfloat16().to(dev).contiguous(memory_format=torch.channels_last)
+    g = GF.raw_conv2d(x, wgt, 1, 1, up2=up2, out_scale=d, bias=b, noise=noise, noise_scale=ns, slope=0.2, pool=pool)
+    dd = GF.raw_conv2d(x, wgt, 1, 1, up2=up2, bias=b, pool=pool, aux=aux, aux_slope=0.2, gain=0.25, resid=res)
+    xl = x.double().cpu()
+    if up2:
+        xl = xl.repeat_interleave(2, 2).repeat_interleave(2, 3)
+    z = F.conv2d(xl, wgt.double().cpu(), padding=1)
+    if pool:
+        z = F.avg_pool2d(z, 2)
+    o1 = F.leaky_relu(z * d.double().cpu().view(n, cout, 1, 1) + b.double().cpu().view(1, -1, 1, 1)
+                      + noise.double().cpu() * ns.double().cpu().view(1, -1, 1, 1), 0.2)
+    o2 = (z * 0.25 + b.double().cpu().view(1, -1, 1, 1)) * torch.where(aux.double().cpu() > 0, 1.0, 0.2) + res.double().cpu()
+    assert rel_err(g, o1) < 4e-3 and rel_err(dd, o2) < 4e-3, (rel_err(g, o1), rel_err(dd, o2))
+    # the same launch without a workspace (nothing splits)
+    wt, cin_p, kpad = GF.pack_weight(wgt, torch.bfloat16, cin_mult=8)
+    xc = GF.as_cl(x)
+    y0 = torch.empty_like(g)
+    rc = lib.gan_conv2d_fwd(xc.data_ptr(), wt.data_ptr(), y0.data_ptr(), None, d.data_ptr(), b.data_ptr(), noise.data_ptr(), ns.data_ptr(), 0.2,
+                            n, h, w, cin_p, int(up2), ho, wo, cout, 3, 3, 1, 1, kpad, 1.0, int(pool), None, 1.0, 1.0, None, 1,
+                            torch.cuda.current_stream().cuda_stream)
+    assert rc == 0 and rel_err(g, y0.float()) < 2e-3
+    need = lib.gan_conv2d_fwd_workspace(n, cin_p, ho, wo, cout, 3, 3, kpad, 0, 1)
+    assert (need > 0) == (n * ho * wo >= 128 and cin % 64 == 0), (need, case)
+
+
 @pytest.mark.parametrize("case", HALO_CASES)
 def test_conv2d_wide_halo_kernel(dev, case, monkeypatch):
     """The resident-halo kernel on every tiling / fused stage, forced also on grids it would leave to conv_wide.hip
