@@ -28,12 +28,29 @@ struct MapParams {
     int L;
 };
 
-// stage W (row-major [t][k]) transposed into LDS: wt[k * WT_PITCH + t]
+// stage W (row-major [t][k]) transposed into LDS: wt[k * WT_PITCH + t].  16-byte loads, all 16 of a thread in flight before
+// the first store (the network is a latency chain: 8 layers x [stage, 128 multiply-adds], a handful of workgroups)
 __device__ __forceinline__ void stage_transposed(const float* __restrict__ W, float* __restrict__ wt) {
-    for (int idx = threadIdx.x; idx < MD * MD; idx += MTPB) {
-        const int t = idx >> 7, k = idx & (MD - 1);
-        wt[k * WT_PITCH + t] = W[idx];
+    float4 v[MD * MD / 4 / MTPB];
+#pragma unroll
+    for (int j = 0; j < MD * MD / 4 / MTPB; ++j) v[j] = reinterpret_cast<const float4*>(W)[j * MTPB + threadIdx.x];
+#pragma unroll
+    for (int j = 0; j < MD * MD / 4 / MTPB; ++j) {
+        const int idx = (j * MTPB + threadIdx.x) * 4, t = idx >> 7, k = idx & (MD - 1);
+        wt[k * WT_PITCH + t] = v[j].x;
+        wt[(k + 1) * WT_PITCH + t] = v[j].y;
+        wt[(k + 2) * WT_PITCH + t] = v[j].z;
+        wt[(k + 3) * WT_PITCH + t] = v[j].w;
     }
+}
+
+// stage W as it is (row-major [t][k]) into LDS: the backward's product g W reads row t, consecutive threads consecutive k
+__device__ __forceinline__ void stage_rows(const float* __restrict__ W, float* __restrict__ wl) {
+    float4 v[MD * MD / 4 / MTPB];
+#pragma unroll
+    for (int j = 0; j < MD * MD / 4 / MTPB; ++j) v[j] = reinterpret_cast<const float4*>(W)[j * MTPB + threadIdx.x];
+#pragma unroll
+    for (int j = 0; j < MD * MD / 4 / MTPB; ++j) reinterpret_cast<float4*>(wl)[j * MTPB + threadIdx.x] = v[j];
 }
 
 __global__ void __launch_bounds__(MTPB) mapping_fwd_k(const float* __restrict__ z, const float* __restrict__ ln_w, const float* __restrict__ ln_b,
@@ -112,6 +129,7 @@ __host__ __device__ constexpr int64_t map_partial_floats(int L) { return (int64_
 __global__ void __launch_bounds__(MTPB) mapping_bwd_k(const float* __restrict__ gout, const float* __restrict__ acts, const float* __restrict__ stats,
                                                       const float* __restrict__ z, const float* __restrict__ ln_w, const MapParams p,
                                                       float* __restrict__ ws, int N, float slope) {
+    extern __shared__ float wl[];      // the layer's weight, MD x MD floats (sized at launch)
     __shared__ float g[MROWS][MD];     // gradient at the layer's output, then at its pre-activation
     __shared__ float prev[MROWS][MD];  // the layer's input
     __shared__ float gn[MROWS][MD];    // gradient at the layer's input
@@ -123,7 +141,8 @@ __global__ void __launch_bounds__(MTPB) mapping_bwd_k(const float* __restrict__ 
         g[r][c] = n < N ? gout[(int64_t)n * MD + c] : 0.f;
     }
     for (int l = p.L - 1; l >= 0; --l) {
-        __syncthreads();
+        __syncthreads();  // g is complete; everyone is done with the previous layer's wl and prev
+        stage_rows(p.W[l], wl);
         const float* __restrict__ yl = acts + (int64_t)(l + 1) * N * MD;
         const float* __restrict__ xl = acts + (int64_t)l * N * MD;
         for (int idx = threadIdx.x; idx < MROWS * MD; idx += MTPB) {
@@ -161,12 +180,11 @@ __global__ void __launch_bounds__(MTPB) mapping_bwd_k(const float* __restrict__ 
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) acc[j][q] = 0.f;
-            const float* __restrict__ W = p.W[l];
 #pragma unroll 2
             for (int tt = 0; tt < MD; tt += 4) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float w = W[(tt + q) * MD + t];  // consecutive threads, consecutive columns: coalesced
+                    const float w = wl[(tt + q) * MD + t];  // consecutive threads, consecutive columns: conflict-free
 #pragma unroll
                     for (int j = 0; j < 4; ++j) acc[j][q] = fmaf(g[half * 4 + j][tt + q], w, acc[j][q]);
                 }
@@ -232,8 +250,8 @@ int check_params(const float* const* W, const float* const* B, int L, MapParams&
     for (int l = 0; l < MAXL; ++l) {
         p.W[l] = l < L ? W[l] : nullptr;
         p.B[l] = (l < L && B) ? B[l] : nullptr;
-        if (l < L && !p.W[l]) {
-            gan_set_error("%s: null weight of layer %d", who, l);
+        if (l < L && (!p.W[l] || ((uintptr_t)p.W[l] & 15))) {
+            gan_set_error("%s: weight of layer %d is null or not 16-byte aligned", who, l);
             return GAN_ERR_ARG;
         }
     }
@@ -271,7 +289,7 @@ extern "C" int gan_mapping_bwd(const float* gout, const float* acts, const float
                   (long long)gan_mapping_bwd_workspace(N, L));
     hipStream_t st = (hipStream_t)stream;
     const int nb = (int)ceil_div64(N, MROWS);
-    hipLaunchKernelGGL(mapping_bwd_k, dim3((unsigned)nb), dim3(MTPB), 0, st, gout, acts, stats, z, ln_w, p, workspace, N, slope);
+    hipLaunchKernelGGL(mapping_bwd_k, dim3((unsigned)nb), dim3(MTPB), sizeof(float) * MD * MD, st, gout, acts, stats, z, ln_w, p, workspace, N, slope);
     GAN_CHECK_LAUNCH("mapping_bwd");
     const int64_t Lf = map_partial_floats(L);
     hipLaunchKernelGGL(mapping_fold_k, dim3((unsigned)ceil_div64(Lf, MTPB)), dim3(MTPB), 0, st, workspace, grads, nb, Lf);
