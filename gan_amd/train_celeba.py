@@ -100,6 +100,31 @@ class Trainer:
         self.autocast_ctx = lambda: torch.autocast(self.device.type, dtype=torch.bfloat16, enabled=cfg.mixed_precision)
         self.step = 0
 
+    # ---- checkpoint / resume (absent in the reference) ------------------------------------------------
+    def state_dict(self) -> Dict:
+        """Everything a resumed run needs: both networks, the EMA copy with its step counter (utils.py:80), both optimizers,
+        the iteration count.  Tensors and plain numbers only: loads with torch.load(weights_only=True)."""
+        return {"step": self.step, "gen": self.gen.state_dict(), "disc": self.disc.state_dict(), "gen_ema": self.gen_ema.state_dict(),
+                "optim_g": self.optim_g.state_dict(), "optim_d": self.optim_d.state_dict()}
+
+    def load_state_dict(self, state: Dict) -> None:
+        self.gen.load_state_dict(state["gen"])
+        self.disc.load_state_dict(state["disc"])
+        self.gen_ema.load_state_dict(state["gen_ema"])
+        self.optim_g.load_state_dict(state["optim_g"])
+        self.optim_d.load_state_dict(state["optim_d"])
+        self.step = int(state["step"])
+        # the parameters were overwritten in place (their arenas stay where the captured graphs read them), but through
+        # copies that packed GEMM images do not notice
+        GF._PACK_CACHE.clear()
+        GF._PAD_MEMO.clear()
+
+    def save_checkpoint(self, path: str) -> None:
+        torch.save(self.state_dict(), path)
+
+    def load_checkpoint(self, path: str) -> None:
+        self.load_state_dict(torch.load(path, map_location=self.device, weights_only=True))
+
     def _broadcast_parameters(self) -> None:
         import torch.distributed as dist
 
