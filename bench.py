@@ -93,7 +93,7 @@ def roofline_leg(trainer, next_reals):
     prof = GF.KernelProfile()
     GF.set_profile(prof)
     try:
-        GF._PACK_CACHE.clear()
+        GF.drop_packed()
         trainer._run_eager(next_reals)  # launched from the host even when the timed steps replay HIP graphs
         torch.cuda.synchronize()
     finally:

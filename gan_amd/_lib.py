@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GAN_AMD_LIB") or os.path.join(_HERE, "libgan_amd.so")
 
 GAN_F32, GAN_BF16 = 0, 1
-ABI_VERSION = 21
+ABI_VERSION = 22
 
 _SIGNATURES = {
     "gan_amd_version": (c_int, []),
@@ -49,13 +49,14 @@ _SIGNATURES = {
     "gan_amd_init": (c_int, []),
     "gan_conv2d_wgrad_static_max_floats": (c_int64, []),
     "gan_conv2d_wgrad_static": (c_int, [c_void_p] * 3 + [c_int, c_int, c_void_p] + [c_int] * 12 + [c_float, c_int, c_float, c_int, c_void_p]),
-    "gan_modconv_bwd_pre": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_void_p]),
+    "gan_modconv_bwd_pre": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_int, c_void_p]),
     "gan_modconv_bwd_post": (c_int, [c_void_p] * 7 + [c_int, c_int, c_void_p]),
-    "gan_scale_dot": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_void_p]),
+    "gan_scale_dot": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_int, c_void_p]),
     "gan_demod_fwd": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p]),
-    "gan_demod_bwd": (c_int, [c_void_p] * 7 + [c_int] * 4 + [c_void_p]),
+    "gan_demod_bwd": (c_int, [c_void_p] * 7 + [c_int] * 5 + [c_void_p]),
     "gan_pack_weight": (c_int, [c_void_p, c_int, c_void_p, c_int] + [c_int] * 7 + [c_void_p]),
     "gan_pad_channels": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int64, c_int64, c_void_p, c_int] + [c_int] * 5 + [c_void_p]),
+    "gan_pack_weights_multi": (c_int, [c_void_p, c_int, c_int64, c_int, c_int, c_void_p]),
     "gan_pack_weight_pair": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int] + [c_int] * 5 + [c_void_p]),
     "gan_up2_add": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "gan_mbstd_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_int, c_void_p]),

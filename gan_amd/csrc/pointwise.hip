@@ -718,14 +718,14 @@ static int modconv_bwd_pre_launch(const void* gy, const void* y, const void* noi
 }
 
 extern "C" int gan_modconv_bwd_pre(const void* gy, const void* y, const void* noise, const float* dinv, float slope, void* gz,
-                                   float* sums, int N, int64_t HW, int C, int dtype, gan_stream_t stream) {
+                                   float* sums, int sums_zeroed, int N, int64_t HW, int C, int dtype, gan_stream_t stream) {
     GAN_CHECK_ARG(N >= 0 && HW >= 0 && C > 0, "modconv_bwd_pre: bad shape");
     GAN_CHECK_ARG(sums && (N == 0 || HW == 0 || (gy && gz)), "modconv_bwd_pre: null pointer");
     GAN_CHECK_ARG(dtype == GAN_F32 || dtype == GAN_BF16, "modconv_bwd_pre: bad dtype %d", dtype);
     hipStream_t st = (hipStream_t)stream;
     const size_t bytes = sizeof(float) * (size_t)N * 3 * C;
     if (bytes == 0) return GAN_OK;
-    if (hipMemsetAsync(sums, 0, bytes, st) != hipSuccess) {
+    if (!sums_zeroed && hipMemsetAsync(sums, 0, bytes, st) != hipSuccess) {
         gan_set_error("modconv_bwd_pre: memset failed");
         return GAN_ERR_LAUNCH;
     }
@@ -797,7 +797,7 @@ static int scale_dot_launch(const void* A, const void* B, const float* a, void* 
     return GAN_OK;
 }
 
-extern "C" int gan_scale_dot(const void* A, const void* B, const float* a, void* out, float* dot, int N, int64_t HW, int C,
+extern "C" int gan_scale_dot(const void* A, const void* B, const float* a, void* out, float* dot, int dot_zeroed, int N, int64_t HW, int C,
                              int dtype, gan_stream_t stream) {
     GAN_CHECK_ARG(N >= 0 && HW >= 0 && C > 0, "scale_dot: bad shape");
     GAN_CHECK_ARG(dot && a && (N == 0 || HW == 0 || (A && B && out)), "scale_dot: null pointer");
@@ -805,7 +805,7 @@ extern "C" int gan_scale_dot(const void* A, const void* B, const float* a, void*
     hipStream_t st = (hipStream_t)stream;
     const size_t bytes = sizeof(float) * (size_t)N * C;
     if (bytes == 0) return GAN_OK;
-    if (hipMemsetAsync(dot, 0, bytes, st) != hipSuccess) {
+    if (!dot_zeroed && hipMemsetAsync(dot, 0, bytes, st) != hipSuccess) {
         gan_set_error("scale_dot: memset failed");
         return GAN_ERR_LAUNCH;
     }
@@ -1240,6 +1240,89 @@ extern "C" int gan_pack_weight_pair(const void* w, int w_dtype, void* out, int c
     return GAN_OK;
 }
 
+// Every GEMM-B image of a list of weights in ONE launch (an iteration packed ~60 weights with ~60 launches of 5-8 us
+// for ~25 us of traffic).  table: `count` rows of 12 int64 in device memory:
+//   [0] w  [1] out (forward image or 0)  [2] out_t (transposed image or 0)  [3] wsq (fp32 [Cout][Cin] tap sums of W^2, or 0)
+//   [4] first workgroup of this row  [5] Cout  [6] Cin  [7] taps  [8] cols_p  [9] Kpad  [10] cols_p_t  [11] Kpad_t
+// A row owns ceil((Cout*Kpad/8 + Cin*Kpad_t/8 + Cout*Cin) / 256) workgroups (absent pieces count 0; both padded row
+// lengths are multiples of 32 and both padded channel counts multiples of 8; images 16-byte aligned, < 2^31 elements).
+// eight consecutive k of one image row (one 16-byte store in bf16): cols_p % 8 == 0, so they share a tap
+template <typename TI, typename TO>
+__device__ __forceinline__ void pack_weight_oct(const TI* __restrict__ w, TO* __restrict__ out, int e, int Cin, int taps, int cols, int cols_p,
+                                                int Kpad, int transposed) {
+    const int k8 = Kpad >> 3;
+    const int r = e / k8, k = (e - r * k8) * 8;
+    const int tap = k / cols_p, c = k - tap * cols_p;
+    TO v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float f = 0.f;
+        if (tap < taps && c + j < cols) {
+            const int co = transposed ? c + j : r, ci = transposed ? r : c + j;
+            const int t = transposed ? taps - 1 - tap : tap;
+            f = (float)w[((int64_t)co * Cin + ci) * taps + t];
+        }
+        v[j] = (TO)f;
+    }
+    TO* __restrict__ dst = out + (int64_t)r * Kpad + k;
+    if (sizeof(TO) == 2) {
+        *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(v);
+    } else {
+        *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(v);
+        *reinterpret_cast<uint4*>(dst + 4) = *reinterpret_cast<const uint4*>(v + 4);
+    }
+}
+
+template <typename TI, typename TO>
+__global__ void __launch_bounds__(256) pack_weights_multi_k(const long long* __restrict__ table, int count) {
+    __shared__ int which;
+    for (int i = threadIdx.x; i < count; i += 256) {
+        const long long b0 = table[i * 12 + 4];
+        const long long b1 = i + 1 < count ? table[(i + 1) * 12 + 4] : (long long)gridDim.x;
+        if ((long long)blockIdx.x >= b0 && (long long)blockIdx.x < b1) which = i;
+    }
+    __syncthreads();
+    const long long* __restrict__ d = table + which * 12;
+    const TI* __restrict__ w = reinterpret_cast<const TI*>(d[0]);
+    TO* __restrict__ out = reinterpret_cast<TO*>(d[1]);
+    TO* __restrict__ out_t = reinterpret_cast<TO*>(d[2]);
+    float* __restrict__ wsq = reinterpret_cast<float*>(d[3]);
+    const int Cout = (int)d[5], Cin = (int)d[6], taps = (int)d[7];
+    // work items of the row: 8-element pieces of the two images, then one (co, ci) tap sum each
+    const int n0 = out ? Cout * ((int)d[9] >> 3) : 0, n1 = out_t ? Cin * ((int)d[11] >> 3) : 0, n2 = wsq ? Cout * Cin : 0;
+    const int e = (int)((long long)blockIdx.x - d[4]) * 256 + threadIdx.x;
+    if (e < n0) {
+        pack_weight_oct<TI, TO>(w, out, e, Cin, taps, Cin, (int)d[8], (int)d[9], 0);
+    } else if (e < n0 + n1) {
+        pack_weight_oct<TI, TO>(w, out_t, e - n0, Cin, taps, Cout, (int)d[10], (int)d[11], 1);
+    } else if (e < n0 + n1 + n2) {
+        const int64_t q = e - n0 - n1;
+        float a = 0.f;
+        for (int t = 0; t < taps; ++t) {
+            const float v = (float)w[q * taps + t];
+            a = fmaf(v, v, a);
+        }
+        wsq[q] = a;
+    }
+}
+
+extern "C" int gan_pack_weights_multi(const int64_t* table, int count, int64_t blocks, int w_dtype, int out_dtype, gan_stream_t stream) {
+    GAN_CHECK_ARG(count >= 0 && blocks >= 0 && blocks < (1LL << 31), "pack_weights_multi: bad sizes");
+    GAN_CHECK_ARG((w_dtype == GAN_F32 || w_dtype == GAN_BF16) && (out_dtype == GAN_F32 || out_dtype == GAN_BF16), "pack_weights_multi: bad dtype");
+    if (count == 0 || blocks == 0) return GAN_OK;
+    GAN_CHECK_ARG(table, "pack_weights_multi: null table");
+    hipStream_t st = (hipStream_t)stream;
+#define PACKM_LAUNCH(TI, TO) \
+    hipLaunchKernelGGL((pack_weights_multi_k<TI, TO>), dim3((unsigned)blocks), dim3(256), 0, st, (const long long*)table, count)
+    if (w_dtype == GAN_F32 && out_dtype == GAN_BF16) PACKM_LAUNCH(float, bf16);
+    else if (w_dtype == GAN_F32) PACKM_LAUNCH(float, float);
+    else if (out_dtype == GAN_BF16) PACKM_LAUNCH(bf16, bf16);
+    else PACKM_LAUNCH(bf16, float);
+#undef PACKM_LAUNCH
+    GAN_CHECK_LAUNCH("pack_weights_multi");
+    return GAN_OK;
+}
+
 // ---- RGB skip of the generator: out = nearest_up2(lo) + hi  (stylegan2.py:99) ---------------------
 // One pass instead of an upsampling pass that materialises the 4x tensor and an add pass.  Rows are treated as
 // flat runs of 2W*C elements, V per thread (16 bytes of hi / out); the matching elements of the half-resolution
@@ -1355,78 +1438,163 @@ __global__ void __launch_bounds__(TPB) wsq_k(const float* __restrict__ w, float*
     wsq[e] = a;
 }
 
-// one wave per (n, co): lanes split ci
-__global__ void __launch_bounds__(TPB) demod_fwd_k(const float* __restrict__ s, const float* __restrict__ wsq, float* __restrict__ dinv,
-                                                   int N, int Cin, int Cout) {
-    const int64_t o = (int64_t)blockIdx.x * (TPB / 64) + (threadIdx.x >> 6);
-    if (o >= (int64_t)N * Cout) return;
-    const int n = (int)(o / Cout), co = (int)(o - (int64_t)n * Cout);
-    float a = 0.f;
-    for (int ci = threadIdx.x & 63; ci < Cin; ci += 64) {
-        const float sv = s[(int64_t)n * Cin + ci];
-        a = fmaf(sv * sv, wsq[(int64_t)co * Cin + ci], a);
-    }
-    for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off);
-    if ((threadIdx.x & 63) == 0) dinv[o] = 1.f / fmaxf(sqrtf(a), 1e-8f);
-}
-
 __device__ __forceinline__ float demod_dq(float g, float d) { return d < 1e8f ? -0.5f * d * d * d * g : 0.f; }
 
-// gs[n][ci] = 2 s[n,ci] * sum_co dq[n,co] * wsq[co,ci]
-__global__ void __launch_bounds__(TPB) demod_bwd_s_k(const float* __restrict__ g, const float* __restrict__ dinv, const float* __restrict__ s,
-                                                     const float* __restrict__ wsq, float* __restrict__ gs, int Cin, int Cout) {
-    extern __shared__ float dq[];
-    const int n = blockIdx.y;
-    for (int co = threadIdx.x; co < Cout; co += TPB) dq[co] = demod_dq(g[(int64_t)n * Cout + co], dinv[(int64_t)n * Cout + co]);
+// The three products of the demodulation factor are small fp32 GEMMs (M, Nn, K out of {N, Cin, Cout}) with an
+// elementwise map on the way in and out:
+//   MODE 0  dinv[n][co] = 1 / max(sqrt(sum_ci s[n,ci]^2 wsq[co,ci]), 1e-8)            M = N,    Nn = Cout, K = Cin
+//   MODE 1  gs[n][ci]   = 2 s[n,ci] sum_co dq[n,co] wsq[co,ci]                         M = N,    Nn = Cin,  K = Cout
+//   MODE 2  gw[co][ci][t] (+)= 2 W[co,ci,t] sum_n dq[n,co] s[n,ci]^2                   M = Cout, Nn = Cin,  K = N
+// One kernel on the exact fp32 MFMA (v_mfma_f32_16x16x4_f32): a workgroup owns a 16 x 16 tile of the result, its four
+// waves split K; a lane loads the operand values of its (row, k) / (k, column) slots straight from global memory --
+// up to 128 k per wave in flight at once, no LDS staging, no barrier in the loop -- and the four partial tiles are
+// summed through LDS in a fixed order.  History: one wave per output re-read the second operand from L2 once per
+// output row (268 MB per call at batch 256: 20-24 us); an LDS-tiled VALU version had 8 workgroups of work at batch 32
+// and a load -> barrier -> compute chain per K chunk (24 us).  This one: M/16 x Nn/16 workgroups, one load round trip.
+struct DemodArgs {
+    const float* g;
+    const float* dinv;
+    const float* s;
+    const float* w;
+    const float* wsq;
+    float* out;
+    int N, Cin, Cout, taps, accum;
+};
+
+template <int MODE>
+__global__ void __launch_bounds__(256) demod_mfma_k(const DemodArgs p) {
+    __shared__ float red[4][256];
+    __shared__ float tile[256];
+    const int M = MODE == 2 ? p.Cout : p.N, Nn = MODE == 0 ? p.Cout : p.Cin, K = MODE == 0 ? p.Cin : (MODE == 1 ? p.Cout : p.N);
+    const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, g = lane >> 4;
+    const int kq = ((((K + 3) >> 2) + 15) >> 4) << 4;  // K range of a wave, a multiple of 16
+    const int kb = wave * kq, ke = min(K, kb + kq);
+    const int m = m0 + i, n = n0 + i;
+    const bool mok = m < M, nok = n < Nn;
+    // rows that are contiguous in k can be read 16 bytes at a time
+    const bool vecA = MODE == 0 ? (p.Cin & 3) == 0 && ((uintptr_t)p.s & 15) == 0
+                                : (MODE == 1 ? (p.Cout & 3) == 0 && (((uintptr_t)p.g | (uintptr_t)p.dinv) & 15) == 0 : false);
+    const bool vecB = MODE == 0 ? (p.Cin & 3) == 0 && ((uintptr_t)p.wsq & 15) == 0 : false;
+    f32x4 c = {0.f, 0.f, 0.f, 0.f};
+    for (int k0 = kb; k0 < ke; k0 += 128) {
+        float a[32], b[32];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int k = k0 + 16 * t + 4 * g;  // this lane's four k of group t
+            // ---- A(m, k..k+3)
+            if (MODE == 0 || MODE == 1) {
+                const int ld = MODE == 0 ? p.Cin : p.Cout;
+                const int64_t off = (int64_t)m * ld + k;
+                float x0[4] = {0.f, 0.f, 0.f, 0.f}, x1[4] = {1.f, 1.f, 1.f, 1.f};
+                if (mok && vecA && k + 3 < ke) {
+                    const float4 v = *reinterpret_cast<const float4*>((MODE == 0 ? p.s : p.g) + off);
+                    x0[0] = v.x; x0[1] = v.y; x0[2] = v.z; x0[3] = v.w;
+                    if (MODE == 1) {
+                        const float4 d = *reinterpret_cast<const float4*>(p.dinv + off);
+                        x1[0] = d.x; x1[1] = d.y; x1[2] = d.z; x1[3] = d.w;
+                    }
+                } else if (mok) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (k + j < ke) {
+                            x0[j] = (MODE == 0 ? p.s : p.g)[off + j];
+                            if (MODE == 1) x1[j] = p.dinv[off + j];
+                        }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) a[4 * t + j] = MODE == 0 ? x0[j] * x0[j] : demod_dq(x0[j], x1[j]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float v = 0.f;
+                    if (mok && k + j < ke) v = demod_dq(p.g[(int64_t)(k + j) * p.Cout + m], p.dinv[(int64_t)(k + j) * p.Cout + m]);
+                    a[4 * t + j] = v;
+                }
+            }
+            // ---- B(k..k+3, n)
+            if (MODE == 0) {
+                const int64_t off = (int64_t)n * p.Cin + k;
+                if (nok && vecB && k + 3 < ke) {
+                    const float4 v = *reinterpret_cast<const float4*>(p.wsq + off);
+                    b[4 * t] = v.x; b[4 * t + 1] = v.y; b[4 * t + 2] = v.z; b[4 * t + 3] = v.w;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) b[4 * t + j] = nok && k + j < ke ? p.wsq[off + j] : 0.f;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float v = 0.f;
+                    if (nok && k + j < ke) {
+                        v = (MODE == 1 ? p.wsq : p.s)[(int64_t)(k + j) * p.Cin + n];
+                        if (MODE == 2) v *= v;
+                    }
+                    b[4 * t + j] = v;
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 32; ++t) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b[t], c, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave][(4 * g + r) * 16 + i] = c[r];
     __syncthreads();
-    const int ci = blockIdx.x * TPB + threadIdx.x;
-    if (ci >= Cin) return;
-    float a = 0.f;
-    for (int co = 0; co < Cout; ++co) a = fmaf(dq[co], wsq[(int64_t)co * Cin + ci], a);
-    gs[(int64_t)n * Cin + ci] = 2.f * s[(int64_t)n * Cin + ci] * a;
+    const int row = tid >> 4, col = tid & 15;
+    const float v = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+    const int mo = m0 + row, no = n0 + col;
+    if (MODE == 0) {
+        if (mo < M && no < Nn) p.out[(int64_t)mo * p.Cout + no] = 1.f / fmaxf(sqrtf(v), 1e-8f);
+    } else if (MODE == 1) {
+        if (mo < M && no < Nn) p.out[(int64_t)mo * p.Cin + no] = 2.f * p.s[(int64_t)mo * p.Cin + no] * v;
+    } else {
+        tile[tid] = v;
+        __syncthreads();
+        if (mo >= M) return;
+        // a row of the tile is min(16, Cin - n0) x taps consecutive floats of W / gw
+        const int run = min(16, Nn - n0) * p.taps;
+        const int64_t base = ((int64_t)mo * p.Cin + n0) * p.taps;
+        for (int e = col; e < run; e += 16) {
+            const float r = 2.f * p.w[base + e] * tile[row * 16 + e / p.taps];
+            p.out[base + e] = p.accum ? p.out[base + e] + r : r;
+        }
+    }
 }
 
-// gw[co][ci][t] = 2 W[co,ci,t] * sum_n dq[n,co] * s[n,ci]^2
-__global__ void __launch_bounds__(TPB) demod_bwd_w_k(const float* __restrict__ g, const float* __restrict__ dinv, const float* __restrict__ s,
-                                                     const float* __restrict__ w, float* __restrict__ gw, int N, int Cin, int Cout, int taps) {
-    extern __shared__ float dq[];
-    const int co = blockIdx.y;
-    for (int n = threadIdx.x; n < N; n += TPB) dq[n] = demod_dq(g[(int64_t)n * Cout + co], dinv[(int64_t)n * Cout + co]);
-    __syncthreads();
-    const int ci = blockIdx.x * TPB + threadIdx.x;
-    if (ci >= Cin) return;
-    float a = 0.f;
-    for (int n = 0; n < N; ++n) {
-        const float sv = s[(int64_t)n * Cin + ci];
-        a = fmaf(dq[n], sv * sv, a);
-    }
-    const int64_t base = ((int64_t)co * Cin + ci) * taps;
-    for (int t = 0; t < taps; ++t) gw[base + t] = 2.f * w[base + t] * a;
+template <int MODE>
+static void demod_launch(const DemodArgs& a, hipStream_t st) {
+    const int M = MODE == 2 ? a.Cout : a.N, Nn = MODE == 0 ? a.Cout : a.Cin;
+    hipLaunchKernelGGL(demod_mfma_k<MODE>, dim3((unsigned)((Nn + 15) / 16), (unsigned)((M + 15) / 16)), dim3(256), 0, st, a);
 }
 
 extern "C" int gan_demod_fwd(const float* s, const float* w, float* wsq, float* dinv, int N, int Cin, int Cout, int taps,
                              gan_stream_t stream) {
-    GAN_CHECK_ARG(s && w && wsq && dinv, "demod_fwd: null pointer");
-    GAN_CHECK_ARG(N > 0 && Cin > 0 && Cout > 0 && taps > 0, "demod_fwd: bad shape");
+    GAN_CHECK_ARG(s && wsq && dinv, "demod_fwd: null pointer");
+    GAN_CHECK_ARG(N > 0 && Cin > 0 && Cout > 0 && taps > 0 && (N + 15) / 16 <= 65535, "demod_fwd: bad shape");
     hipStream_t st = (hipStream_t)stream;
-    const int64_t ne = (int64_t)Cout * Cin;
-    hipLaunchKernelGGL(wsq_k, dim3((unsigned)ceil_div64(ne, TPB)), dim3(TPB), 0, st, w, wsq, ne, taps);
-    const int64_t blocks = ceil_div64((int64_t)N * Cout, TPB / 64);
-    GAN_CHECK_ARG(blocks < (1LL << 31), "demod_fwd: too large");
-    hipLaunchKernelGGL(demod_fwd_k, dim3((unsigned)blocks), dim3(TPB), 0, st, s, wsq, dinv, N, Cin, Cout);
+    if (w) {  // w == NULL: wsq already holds the tap sums of this weight (gan_pack_weights_multi writes them)
+        const int64_t ne = (int64_t)Cout * Cin;
+        hipLaunchKernelGGL(wsq_k, dim3((unsigned)ceil_div64(ne, TPB)), dim3(TPB), 0, st, w, wsq, ne, taps);
+    }
+    DemodArgs a{nullptr, nullptr, s, nullptr, wsq, dinv, N, Cin, Cout, taps, 0};
+    demod_launch<0>(a, st);
     GAN_CHECK_LAUNCH("demod_fwd");
     return GAN_OK;
 }
 
 extern "C" int gan_demod_bwd(const float* g, const float* dinv, const float* s, const float* w, const float* wsq, float* gs,
-                             float* gw, int N, int Cin, int Cout, int taps, gan_stream_t stream) {
+                             float* gw, int gw_accumulate, int N, int Cin, int Cout, int taps, gan_stream_t stream) {
     GAN_CHECK_ARG(g && dinv && s && w && wsq, "demod_bwd: null pointer");
-    GAN_CHECK_ARG(N > 0 && Cin > 0 && Cout > 0 && taps > 0 && N <= 65535 && Cout <= 65535, "demod_bwd: bad shape");
-    GAN_CHECK_ARG((size_t)Cout * 4 <= 64 * 1024 && (size_t)N * 4 <= 64 * 1024, "demod_bwd: N or Cout too large for the LDS row");
+    GAN_CHECK_ARG(N > 0 && Cin > 0 && Cout > 0 && taps > 0 && (N + 15) / 16 <= 65535 && (Cout + 15) / 16 <= 65535, "demod_bwd: bad shape");
     hipStream_t st = (hipStream_t)stream;
-    const unsigned gx = (unsigned)((Cin + TPB - 1) / TPB);
-    if (gs) hipLaunchKernelGGL(demod_bwd_s_k, dim3(gx, (unsigned)N), dim3(TPB), (size_t)Cout * 4, st, g, dinv, s, wsq, gs, Cin, Cout);
-    if (gw) hipLaunchKernelGGL(demod_bwd_w_k, dim3(gx, (unsigned)Cout), dim3(TPB), (size_t)N * 4, st, g, dinv, s, w, gw, N, Cin, Cout, taps);
+    if (gs) {
+        DemodArgs a{g, dinv, s, w, wsq, gs, N, Cin, Cout, taps, 0};
+        demod_launch<1>(a, st);
+    }
+    if (gw) {
+        DemodArgs a{g, dinv, s, w, wsq, gw, N, Cin, Cout, taps, gw_accumulate};
+        demod_launch<2>(a, st);
+    }
     GAN_CHECK_LAUNCH("demod_bwd");
     return GAN_OK;
 }

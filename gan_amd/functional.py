@@ -239,6 +239,62 @@ def raw_chan_dot(A: Tensor, B: Optional[Tensor], b_mode: int, ymask: Optional[Te
     return out
 
 
+# ---- one memset for the accumulation targets of a whole backward pass ------------------------------------------
+# gan_modconv_bwd_pre / gan_scale_dot add their workgroups' partial sums into small (N, C)-sized buffers that must
+# start at zero: a memset launch per call, ~33 per generator backward.  Inside `zeroed_scratch(device)` those buffers
+# are slices of one per-device pool cleared once on entry.  The pool is recycled by the next `zeroed_scratch` on the
+# device, so only a caller that has consumed the pass's results by then (a trainer around loss.backward()) opts in.
+_ZERO_POOL: dict = {}
+
+
+@contextlib.contextmanager
+def zeroed_scratch(device):
+    device = torch.device(device)
+    if device.type != "cuda":
+        yield
+        return
+    if device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    st = _ZERO_POOL.setdefault(device, {"buf": None, "cursor": 0, "need": 0, "want": 0, "active": False})
+    if st["active"]:
+        yield
+        return
+    st["want"] = max(st["want"], st["need"])
+    have = st["buf"].numel() if st["buf"] is not None else 0
+    if st["want"] > have and not torch.cuda.is_current_stream_capturing():  # (an allocation made while capturing would belong to the graph)
+        st["buf"] = torch.empty((st["want"] + st["want"] // 4 + 4096,), dtype=torch.float32, device=device)
+    if st["buf"] is not None:
+        st["buf"].zero_()
+    st["cursor"], st["need"], st["active"] = 0, 0, True
+    try:
+        yield
+    finally:
+        st["active"] = False
+
+
+def grow_zero_pool() -> None:
+    """Size every device's pool to what its last pass asked for (call outside stream capture)."""
+    for device, st in _ZERO_POOL.items():
+        st["want"] = max(st["want"], st["need"])
+        if st["want"] > (st["buf"].numel() if st["buf"] is not None else 0) and not st["active"]:
+            st["buf"] = torch.empty((st["want"] + st["want"] // 4 + 4096,), dtype=torch.float32, device=device)
+
+
+def _zeroed(nfloats: int, device) -> Optional[Tensor]:
+    """A zero-filled fp32 slice of the active pool, or None (no pool active on the device, or it is exhausted: the next
+    `zeroed_scratch` grows it)."""
+    st = _ZERO_POOL.get(device)
+    if st is None or not st["active"]:
+        return None
+    n = nfloats + ((-nfloats) % 64)
+    st["need"] += n
+    if st["buf"] is None or st["cursor"] + n > st["buf"].numel():
+        return None
+    out = st["buf"][st["cursor"] : st["cursor"] + nfloats]
+    st["cursor"] += n
+    return out
+
+
 def raw_modconv_bwd_pre(gy: Tensor, y: Optional[Tensor], noise: Optional[Tensor], dinv: Optional[Tensor], slope: float):
     """One pass: gz = gy*m(y)*dinv and the per-sample sums (N, 3, C) [gy*m, gy*m*noise, gy*y] (include/gan_amd.h)."""
     require_gpu(gy, y, noise, dinv)
@@ -253,12 +309,13 @@ def raw_modconv_bwd_pre(gy: Tensor, y: Optional[Tensor], noise: Optional[Tensor]
     if d32 is not None and d32.numel() != n * c:
         d32 = d32.reshape(1, c).expand(n, c).contiguous()
     gz = _empty_like_cl(gy, gy.shape)
-    sums = torch.empty((n, 3, c), dtype=torch.float32, device=gy.device)
+    zeroed = _zeroed(n * 3 * c, gy.device)
+    sums = zeroed.view(n, 3, c) if zeroed is not None else torch.empty((n, 3, c), dtype=torch.float32, device=gy.device)
     check(
         _run(
             "modconv_bwd_pre", 0, _nbytes(gy, y, noise, gz),
-            lambda: lib.gan_modconv_bwd_pre(ptr(gy), ptr(y), ptr(noise), ptr(d32), float(slope), ptr(gz), ptr(sums), n, h * w, c,
-                                            dtype_code(gy), stream_of(gy)),
+            lambda: lib.gan_modconv_bwd_pre(ptr(gy), ptr(y), ptr(noise), ptr(d32), float(slope), ptr(gz), ptr(sums), int(zeroed is not None),
+                                            n, h * w, c, dtype_code(gy), stream_of(gy)),
             (n, c, h, w),
         ),
         "gan_modconv_bwd_pre",
@@ -290,11 +347,13 @@ def raw_scale_dot(A: Tensor, B: Tensor, a: Tensor):
     n, c, h, w = A.shape
     a32 = _f32(a).reshape(n, c).contiguous()
     out = _empty_like_cl(A, A.shape)
-    dot = torch.empty((n, c), dtype=torch.float32, device=A.device)
+    zeroed = _zeroed(n * c, A.device)
+    dot = zeroed.view(n, c) if zeroed is not None else torch.empty((n, c), dtype=torch.float32, device=A.device)
     check(
         _run(
             "scale_dot", 0, _nbytes(A, B, out),
-            lambda: lib.gan_scale_dot(ptr(A), ptr(B), ptr(a32), ptr(out), ptr(dot), n, h * w, c, dtype_code(A), stream_of(A)),
+            lambda: lib.gan_scale_dot(ptr(A), ptr(B), ptr(a32), ptr(out), ptr(dot), int(zeroed is not None), n, h * w, c, dtype_code(A),
+                                      stream_of(A)),
             (n, c, h, w),
         ),
         "gan_scale_dot",
@@ -433,6 +492,14 @@ def pack_weight(weight: Tensor, dtype: torch.dtype, cin_mult: int = 8, transpose
 PACK_STATS = [0, 0]  # hits, misses (cacheable tensors only)
 
 
+def drop_packed() -> None:
+    """Forget every cached GEMM image, tap sum and padded input (a graph replay or an in-place load changed the weights
+    without bumping their versions; buffers recorded during an aborted capture were never written)."""
+    _PACK_CACHE.clear()
+    _WSQ_CACHE.clear()
+    _PAD_MEMO.clear()
+
+
 def invalidate_packed(params) -> None:
     """Drop the cached GEMM images of `params`: for writers that change a parameter's values behind autograd's
     back -- through a flat arena or a raw pointer (EMA.step, a graph replay) -- so that neither `_version` nor
@@ -440,6 +507,110 @@ def invalidate_packed(params) -> None:
     ids = {id(p) for p in params}
     for key in [k for k in _PACK_CACHE if k[0] in ids]:
         del _PACK_CACHE[key]
+    for i in ids:
+        _WSQ_CACHE.pop(i, None)
+
+
+# ---- all packed images of a network in one launch -----------------------------------------------------------
+# tap sums of W^2 per (co, ci) of the modulated convolutions' weights (DemodFn's first factor), by id(weight)
+_WSQ_CACHE: dict = {}
+_WSQ_SEEN: dict = {}
+_DT_CODE = {torch.float32: _lib.GAN_F32, torch.bfloat16: _lib.GAN_BF16}
+_PREPACK_GROUPS: dict = {}
+
+
+def _cache_valid(key, weight: Tensor) -> bool:
+    hit = _PACK_CACHE.get(key)
+    return hit is not None and hit[0]() is weight and hit[1] == (weight._version, weight.data_ptr())
+
+
+def prepack_weights(weights) -> bool:
+    """Re-pack, in ONE launch (gan_pack_weights_multi), every GEMM image the earlier passes asked of these conv weights
+    (pack_weight records the orientations in _PACK_SEEN) and the tap sums DemodFn asked for, into buffers that live as
+    long as the group, and point the caches at them.  A trainer calls this after an optimizer step instead of letting
+    ~60 convolutions each find a stale cache entry and pack their own weight (5-8 us per launch for ~25 us of traffic).
+    Returns False when nothing was launched: images all current, nothing recorded yet, or the group's table would
+    have to be built (a host-to-device copy) while the stream is being captured."""
+    weights = [w for w in weights if w.dim() == 4 and w.is_cuda and w.dtype in (torch.float32, torch.bfloat16) and w.is_contiguous()]
+    if not weights:
+        return False
+    plan, stale = [], False
+    for w in weights:
+        wsq = _WSQ_SEEN.get(id(w))
+        want_wsq = wsq is not None and wsq() is w
+        if want_wsq:
+            hit = _WSQ_CACHE.get(id(w))
+            stale |= not (hit is not None and hit[0]() is w and hit[1] == (w._version, w.data_ptr()))
+        for dt in (torch.bfloat16, torch.float32):
+            seen = _PACK_SEEN.get((id(w), dt))
+            if seen is None or seen[0]() is not w:
+                continue
+            fwd = sorted(m for m, t in seen[1] if not t)
+            tr = sorted(m for m, t in seen[1] if t)
+            if len(fwd) > 1 or len(tr) > 1 or (not fwd and not tr):
+                continue  # several paddings of one orientation: left to pack_weight
+            plan.append((w, dt, fwd[0] if fwd else None, tr[0] if tr else None, want_wsq))
+            want_wsq = False
+            for m, t in seen[1]:
+                stale |= not _cache_valid((id(w), dt, m, t), w)
+        if want_wsq:
+            plan.append((w, torch.float32, None, None, True))
+    if not plan or not stale:
+        return False
+    gkey = tuple(id(w) for w in weights)
+    sig = tuple((id(w), w.data_ptr(), dt, mf, mt, q) for w, dt, mf, mt, q in plan)
+    group = _PREPACK_GROUPS.get(gkey)
+    if group is None or group["sig"] != sig:
+        if torch.cuda.is_current_stream_capturing():
+            return False
+        if len(_PREPACK_GROUPS) > 64:
+            _PREPACK_GROUPS.clear()
+        dev = weights[0].device
+        launches: dict = {}
+        entries = []
+        for w, dt, mf, mt, q in plan:
+            cout, cin, kh, kw = w.shape
+            taps = kh * kw
+            img_f = img_t = wsq = None
+            row = [w.data_ptr(), 0, 0, 0, 0, cout, cin, taps, 0, 0, 0, 0]
+            n = 0
+            if mf is not None:
+                cp = cin + ((-cin) % mf)
+                kpad = taps * cp + ((-taps * cp) % 32)
+                img_f = (_packed_rows(cout, kpad, dt, dev), cp, kpad)
+                row[1], row[8], row[9] = img_f[0].data_ptr(), cp, kpad
+                n += cout * kpad // 8
+            if mt is not None:
+                cp = cout + ((-cout) % mt)
+                kpad = taps * cp + ((-taps * cp) % 32)
+                img_t = (_packed_rows(cin, kpad, dt, dev), cp, kpad)
+                row[2], row[10], row[11] = img_t[0].data_ptr(), cp, kpad
+                n += cin * kpad // 8
+            if q:
+                wsq = torch.empty((cout, cin), dtype=torch.float32, device=dev)
+                row[3] = wsq.data_ptr()
+                n += cout * cin
+            tab = launches.setdefault((w.dtype, dt), {"rows": [], "blocks": 0})
+            row[4] = tab["blocks"]
+            tab["blocks"] += -(-n // 256)
+            tab["rows"].append(row)
+            entries.append((w, dt, mf, mt, img_f, img_t, wsq))
+        for tab in launches.values():
+            tab["table"] = torch.tensor(tab["rows"], dtype=torch.int64, device=dev)
+        group = _PREPACK_GROUPS[gkey] = {"sig": sig, "launches": launches, "entries": entries, "keep": [weakref.ref(w) for w in weights]}
+    lib = _lib.load()
+    for (wdt, odt), tab in group["launches"].items():
+        check(lib.gan_pack_weights_multi(ptr(tab["table"]), len(tab["rows"]), tab["blocks"], _DT_CODE[wdt], _DT_CODE[odt],
+                                         stream_of(tab["table"])), "gan_pack_weights_multi")
+    for w, dt, mf, mt, img_f, img_t, wsq in group["entries"]:
+        ref, ver = weakref.ref(w), (w._version, w.data_ptr())
+        if img_f is not None:
+            _PACK_CACHE[(id(w), dt, mf, False)] = (ref, ver, img_f)
+        if img_t is not None:
+            _PACK_CACHE[(id(w), dt, mt, True)] = (ref, ver, img_t)
+        if wsq is not None:
+            _WSQ_CACHE[id(w)] = (ref, ver, wsq)
+    return True
 
 
 def _wide_kernel_shape(x: Tensor, cin_p: int, cout: int, ho: int, wo: int, kh: int, kw: int, py: int, px: int) -> bool:
@@ -719,6 +890,8 @@ def _bias_grad_for(b: Tensor, g: Tensor) -> Optional[Tensor]:
     if slot is not None and slot.numel() == g.shape[1]:
         raw_chan_dot(g, None, 0, None, 1.0, False, into=slot)
         return None
+    if isinstance(b, torch.nn.Parameter):
+        b._gan_direct = True  # FlatArena.begin_direct: give this parameter a zeroed gradient slice from the next pass on
     return ChanSumFn.apply(g, False).reshape(b.shape).to(b.dtype)
 
 
@@ -930,7 +1103,7 @@ class DBlockInputFn(Function):
             s = raw_conv2d(xs, ws, 0, 0, bias=bs)
         ctx.save_for_backward(x, w1, b1, ws, xs)
         ctx.cfg = (pad, slope, pool_in_conv)
-        ctx.bs_meta = None if bs is None else (bs.shape, bs.dtype)
+        ctx.bs = bs  # (a parameter: held by the module anyway)
         return p1, s
 
     @staticmethod
@@ -938,8 +1111,8 @@ class DBlockInputFn(Function):
         x, w1, b1, ws, xs = ctx.saved_tensors
         pad, slope, pool_in_conv = ctx.cfg
         gx = gw1 = gb1 = gws = gbs = None
-        if ctx.bs_meta is not None and _need(ctx, 6):
-            gbs = ChanSumFn.apply(g_s, False).reshape(ctx.bs_meta[0]).to(ctx.bs_meta[1])
+        if ctx.bs is not None and _need(ctx, 6):
+            gbs = _bias_grad_for(ctx.bs, g_s)
         if _need(ctx, 0):
             if pool_in_conv:
                 gx_s = Conv2dDgradFn.apply(g_s, ws, 0, 0, None, 1.0, True)
@@ -1253,9 +1426,18 @@ class DemodFn(Function):
         w32 = weight.detach().float().contiguous()
         n, cin = s32.shape
         cout, taps = w32.shape[0], w32.shape[2] * w32.shape[3]
-        wsq = torch.empty((cout, cin), dtype=torch.float32, device=s.device)
         dinv = torch.empty((n, cout), dtype=torch.float32, device=s.device)
-        check(lib.gan_demod_fwd(ptr(s32), ptr(w32), ptr(wsq), ptr(dinv), n, cin, cout, taps, stream_of(s32)), "gan_demod_fwd")
+        hit = _WSQ_CACHE.get(id(weight))
+        if hit is not None and hit[0]() is weight and hit[1] == (weight._version, weight.data_ptr()):
+            wsq = hit[2]  # written with the packed images (prepack_weights)
+            check(lib.gan_demod_fwd(ptr(s32), None, ptr(wsq), ptr(dinv), n, cin, cout, taps, stream_of(s32)), "gan_demod_fwd")
+        else:
+            if isinstance(weight, torch.nn.Parameter) and weight.dtype == torch.float32:
+                if len(_WSQ_SEEN) > 4096:
+                    _WSQ_SEEN.clear()
+                _WSQ_SEEN[id(weight)] = weakref.ref(weight)
+            wsq = torch.empty((cout, cin), dtype=torch.float32, device=s.device)
+            check(lib.gan_demod_fwd(ptr(s32), ptr(w32), ptr(wsq), ptr(dinv), n, cin, cout, taps, stream_of(s32)), "gan_demod_fwd")
         ctx.save_for_backward(s, weight, wsq, dinv)
         return dinv
 
@@ -1277,10 +1459,11 @@ class DemodFn(Function):
         cout, taps = w32.shape[0], w32.shape[2] * w32.shape[3]
         g = g.detach().float().contiguous()
         gs = torch.empty_like(s32) if _need(ctx, 0) else None
-        gw = torch.empty_like(w32) if _need(ctx, 1) else None
-        check(lib.gan_demod_bwd(ptr(g), ptr(dinv), ptr(s32), ptr(w32), ptr(wsq), ptr(gs), ptr(gw), n, cin, cout, taps, stream_of(g)),
-              "gan_demod_bwd")
-        return (gs.to(s.dtype) if gs is not None else None), (gw.to(weight.dtype) if gw is not None else None)
+        slot = grad_slot(weight) if _need(ctx, 1) and weight.dtype == torch.float32 else None
+        gw = slot if slot is not None else (torch.empty_like(w32) if _need(ctx, 1) else None)
+        check(lib.gan_demod_bwd(ptr(g), ptr(dinv), ptr(s32), ptr(w32), ptr(wsq), ptr(gs), ptr(gw), int(slot is not None), n, cin, cout, taps,
+                                stream_of(g)), "gan_demod_bwd")
+        return (gs.to(s.dtype) if gs is not None else None), (gw.to(weight.dtype) if gw is not None and slot is None else None)
 
 
 class MbstdFn(Function):

@@ -99,6 +99,8 @@ class Trainer:
         self.optim_g = make_optimizer(cfg.optimizer, self.gen, cfg.lr, okw, capturable=cfg.hip_graph)
         self.autocast_ctx = lambda: torch.autocast(self.device.type, dtype=torch.bfloat16, enabled=cfg.mixed_precision)
         self.step = 0
+        self._conv_w_g = [p for p in self.gen.parameters() if p.dim() == 4]
+        self._conv_w_d = [p for p in self.disc.parameters() if p.dim() == 4]
 
     # ---- checkpoint / resume (absent in the reference) ------------------------------------------------
     def state_dict(self) -> Dict:
@@ -116,8 +118,7 @@ class Trainer:
         self.step = int(state["step"])
         # the parameters were overwritten in place (their arenas stay where the captured graphs read them), but through
         # copies that packed GEMM images do not notice
-        GF._PACK_CACHE.clear()
-        GF._PAD_MEMO.clear()
+        GF.drop_packed()
 
     def save_checkpoint(self, path: str) -> None:
         torch.save(self.state_dict(), path)
@@ -188,8 +189,10 @@ class Trainer:
                 return self._run_eager(next_reals)
             n_fetch = cfg.n_disc * cfg.grad_accum
             self._graph_reals = [next_reals().clone() for _ in range(n_fetch)]
-            GF._PACK_CACHE.clear()  # every packed weight the graphs read must be packed inside them
-            GF._PAD_MEMO.clear()
+            GF.grow_zero_pool()
+            GF.prepack_weights(self._conv_w_g)  # builds the groups' tables (a host-to-device copy: not capturable)
+            GF.prepack_weights(self._conv_w_d)
+            GF.drop_packed()  # every packed weight the graphs read must be packed inside them
             feed = iter(self._graph_reals)
             # `.detach()`: an alias, so that requires_grad_ stays off the static buffer
             it = self._iteration(lambda: next(feed).detach(), overlap=False)
@@ -233,8 +236,7 @@ class Trainer:
                 self.disc.requires_grad_(True)
                 # what the aborted capture left behind was recorded, never executed: packed weights and padded inputs
                 # that point at graph-pool buffers, gradient tensors handed over by a backward pass that did not run
-                GF._PACK_CACHE.clear()
-                GF._PAD_MEMO.clear()
+                GF.drop_packed()
                 for red in (self.red_d, self.red_g):
                     red.arena.attach_grads()
                     red.zero_grad()
@@ -250,8 +252,7 @@ class Trainer:
             graph.replay()
             if cut is not None:
                 self._exchange(*cut)
-        GF._PACK_CACHE.clear()  # a replay updates the weights without bumping their Python-side versions
-        GF._PAD_MEMO.clear()
+        GF.drop_packed()  # a replay updates the weights without bumping their Python-side versions
         return {k: v.clone() for k, v in self._graph_logs.items()}
 
     def _iteration(self, next_reals: Callable[[], Tensor], overlap: bool):
@@ -267,6 +268,11 @@ class Trainer:
         the backward is nearly over; and G's large tensors (512-channel blocks) are the LAST its backward reaches.
         Returns the log dict."""
         cfg, disc, gen = self.cfg, self.disc, self.gen
+        # every GEMM image of both networks' conv weights in one launch each (the generator's changed at the end of
+        # the last iteration; the discriminator's are current unless the caches were dropped, as before a capture --
+        # so a replayed iteration starts by packing what it reads, whoever changed the weights)
+        GF.prepack_weights(self._conv_w_g)
+        GF.prepack_weights(self._conv_w_d)
         early_g = None  # (zs, generator output) of the G step when its forward ran under D's all-reduce
         for i in range(cfg.n_disc):
             cached_reals: Optional[List[Tensor]] = [] if i == cfg.n_disc - 1 else None
@@ -309,6 +315,7 @@ class Trainer:
                         else:
                             yield ("reduce", self.red_d)
             self.optim_d.step()
+            GF.prepack_weights(self._conv_w_d)
             if overlap:
                 self.red_d.zero_grad()
 
@@ -325,7 +332,7 @@ class Trainer:
                     self.red_g.prepare()
                 if a == 0 and not overlap:
                     self.red_g.arena.begin_direct()
-                with GF.direct_param_grads(not overlap):
+                with GF.direct_param_grads(not overlap), GF.zeroed_scratch(self.device):
                     loss_g.backward()
                 if last and overlap:
                     self.red_g.finish()

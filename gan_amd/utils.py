@@ -127,9 +127,10 @@ class FlatArena:
         for p in self.params:
             p.grad = None
 
-    def begin_direct(self, select=lambda p: p.dim() == 4) -> None:
+    def begin_direct(self, select=lambda p: p.dim() == 4 or getattr(p, "_gan_direct", False)) -> None:
         """Before a backward pass run under functional.direct_param_grads(): the parameters `select` picks (conv
-        weights: the tensors whose gradients the wgrad kernels can add in place) get their ZEROED arena slices as
+        weights: the tensors whose gradients the wgrad kernels can add in place; biases that functional._bias_grad_for
+        has marked as summed by the channel-sum kernel) get their ZEROED arena slices as
         .grad, every other parameter None (autograd then hands its first gradient over for free); gather_grads()
         files the rest afterwards."""
         views = []

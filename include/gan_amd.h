@@ -98,9 +98,11 @@ int gan_chan_dot(const void* A, const void* B, int b_mode, const void* ymask, fl
  *        gdinv[n][c] = (sums[n][2][c] - sums[n][0][c]*bias[c] - sums[n][1][c]*ns[c]) / dinv[n][c]
  *        (bias / ns NULL = 0; all fp32). */
 int gan_modconv_bwd_pre(const void* gy, const void* y, const void* noise, const float* dinv, float slope, void* gz,
-                        float* sums, int N, int64_t HW, int C, int dtype, gan_stream_t stream);
-int gan_scale_dot(const void* A, const void* B, const float* a, void* out, float* dot, int N, int64_t HW, int C, int dtype,
-                  gan_stream_t stream);
+                        float* sums, int sums_zeroed, int N, int64_t HW, int C, int dtype, gan_stream_t stream);
+int gan_scale_dot(const void* A, const void* B, const float* a, void* out, float* dot, int dot_zeroed, int N, int64_t HW, int C,
+                  int dtype, gan_stream_t stream);
+/* (sums_zeroed / dot_zeroed != 0: the caller hands over a buffer that already holds zeros -- one memset for all the
+ * layers of a backward pass instead of one per call; 0: the call clears it on `stream` first.) */
 int gan_modconv_bwd_post(const float* sums, const float* bias, const float* ns, const float* dinv, float* gb, float* gns,
                          float* gdinv, int N, int C, gan_stream_t stream);
 
@@ -108,11 +110,12 @@ int gan_modconv_bwd_post(const float* sums, const float* bias, const float* ns, 
  * (modelling/stylegan2.py:33) by dinv[n][co] = 1 / max(sqrt(sum_ci s[n,ci]^2 * wsq[co,ci]), 1e-8),
  * wsq[co][ci] = sum_taps W^2 (written here: a [Cout][Cin] scratch the caller owns and hands back to the
  * backward).  All fp32; s: [N][Cin], w: [Cout][Cin][taps].  Backward: gs [N][Cin] and / or gw [Cout][Cin][taps]
- * (either may be NULL) from g = d loss / d dinv. */
+ * (either may be NULL) from g = d loss / d dinv; gw_accumulate != 0 adds into gw (a parameter's gradient buffer).
+ * gan_demod_fwd with w == NULL takes wsq as given (gan_pack_weights_multi writes it with the packed images). */
 int gan_demod_fwd(const float* s, const float* w, float* wsq, float* dinv, int N, int Cin, int Cout, int taps,
                   gan_stream_t stream);
 int gan_demod_bwd(const float* g, const float* dinv, const float* s, const float* w, const float* wsq, float* gs,
-                  float* gw, int N, int Cin, int Cout, int taps, gan_stream_t stream);
+                  float* gw, int gw_accumulate, int N, int Cin, int Cout, int taps, gan_stream_t stream);
 
 /* ---- implicit-GEMM convolution (MFMA) ----------------------------------------------------
  * replaces ModulatedConv2d.forward / batched_conv2d   modelling/stylegan2.py:18-36
@@ -208,6 +211,14 @@ int gan_pack_weight(const void* w, int w_dtype, void* out, int out_dtype, int Co
  * as transposed = 1 with (cols_p_t, Kpad_t).  Every layer that trains uses both (forward + input gradient). */
 int gan_pack_weight_pair(const void* w, int w_dtype, void* out, int cols_p, int Kpad, void* out_t, int cols_p_t, int Kpad_t,
                          int out_dtype, int Cout, int Cin, int kh, int kw, gan_stream_t stream);
+/* The images of a LIST of weights in one launch (the reference re-reads its weights in every F.conv2d; here they are
+ * re-packed once per optimizer step, and ~60 launches of 5-8 us per iteration become two).  `table`: device memory,
+ * `count` rows of 12 int64: [0] w, [1] out or 0, [2] out_t or 0, [3] wsq (fp32 [Cout][Cin] sums over the taps of W^2,
+ * the first factor of gan_demod_fwd) or 0, [4] first workgroup of the row, [5] Cout, [6] Cin, [7] kh*kw, [8] cols_p,
+ * [9] Kpad, [10] cols_p_t, [11] Kpad_t; a row owns ceil((Cout*Kpad/8 + Cin*Kpad_t/8 + Cout*Cin) / 256) workgroups
+ * (absent pieces count 0; a thread writes 8 consecutive k: cols_p % 8 == 0, Kpad % 32 == 0, images 16-byte aligned) and
+ * `blocks` is their total.  All rows share w_dtype and out_dtype. */
+int gan_pack_weights_multi(const int64_t* table, int count, int64_t blocks, int w_dtype, int out_dtype, gan_stream_t stream);
 
 /* Image-like tensors (C < 8: the RGB inputs / outputs of the from-RGB and to-RGB convolutions,
  * progressive_gan.py:61, stylegan2.py:124) -> channels-last, zero padded to Cp channels (multiple of 8), in

@@ -816,7 +816,7 @@ def test_pack_weight_pair(dev, shape):
     cout, cin = shape[0], shape[1]
     mf, mt = (16 if cin < 8 else 8), (16 if cout < 8 else 8)
     for dtype in (torch.bfloat16, torch.float32):
-        GF._PACK_CACHE.clear()
+        GF.drop_packed()
         GF._PACK_SEEN.clear()
         f0 = GF._pack_weight(w.detach(), dtype, mf, False)
         t0 = GF._pack_weight(w.detach(), dtype, mt, True)
@@ -830,6 +830,60 @@ def test_pack_weight_pair(dev, shape):
         assert GF.PACK_STATS[1] == miss0 + 1  # one (paired) launch served both
         for a, b in ((f0, f1), (t0, t1)):
             assert a[1:] == b[1:] and torch.equal(a[0], b[0])
+
+
+def test_prepack_weights_multi(dev):
+    """gan_pack_weights_multi: every image (and DemodFn's tap sums) of a list of weights from one launch == the single
+    packs bit for bit; the caches then serve pack_weight / DemodFn without a launch; a second call with nothing stale does
+    nothing; a weight changed in place (version bump) is re-packed into the SAME buffers; the weight gradient of the
+    demodulation factor adds into a gradient buffer (gw_accumulate)."""
+    import gan_amd.functional as GF
+
+    g = torch.Generator().manual_seed(12)
+    shapes = [(32, 16, 3, 3), (16, 3, 1, 1), (513, 24, 3, 3), (24, 40, 3, 3), (8, 8, 1, 1)]
+    ws = [torch.nn.Parameter(torch.randn(*sh, generator=g).to(dev)) for sh in shapes]
+    GF.drop_packed()
+    GF._PACK_SEEN.clear()
+    GF._WSQ_SEEN.clear()
+    GF._PREPACK_GROUPS.clear()
+    assert GF.prepack_weights(ws) is False  # nothing asked for yet
+    want = {}
+    for i, w in enumerate(ws):
+        cout, cin = w.shape[:2]
+        mf, mt = (16 if cin < 8 else 8), (16 if cout < 8 else 8)
+        if i != 1:
+            want[(i, False)] = (mf, GF.pack_weight(w, torch.bfloat16, mf, False))
+        if i != 3:
+            want[(i, True)] = (mt, GF.pack_weight(w, torch.bfloat16, mt, True))
+    s = (torch.randn(5, 40, generator=g) * 0.5 + 1).to(dev)
+    d0 = GF.DemodFn.apply(s, ws[3])  # records ws[3] as a demodulated weight
+    GF.drop_packed()
+    assert GF.prepack_weights(ws) is True
+    miss0 = GF.PACK_STATS[1]
+    bufs = {}
+    for (i, tr), (m, ref) in want.items():
+        got = GF.pack_weight(ws[i], torch.bfloat16, m, tr)
+        assert got[1:] == ref[1:] and torch.equal(got[0], ref[0]), (i, tr)
+        bufs[(i, tr)] = got[0].data_ptr()
+    assert GF.PACK_STATS[1] == miss0  # all served from the group's buffers
+    hit = GF._WSQ_CACHE[id(ws[3])]
+    assert torch.equal(hit[2], ws[3].detach().square().sum(dim=(2, 3)))  or rel_err(hit[2], ws[3].detach().double().square().sum(dim=(2, 3))) < 1e-6
+    assert torch.equal(GF.DemodFn.apply(s, ws[3]), d0)
+    assert GF.prepack_weights(ws) is False  # nothing stale
+    with torch.no_grad():
+        ws[0].mul_(2.0)
+    assert GF.prepack_weights(ws) is True
+    got = GF.pack_weight(ws[0], torch.bfloat16, 8, False)
+    assert got[0].data_ptr() == bufs[(0, False)] and torch.equal(got[0], GF._pack_weight(ws[0].detach(), torch.bfloat16, 8, False)[0])
+    # demodulation weight gradient added into .grad
+    w = ws[3]
+    sg = s.clone().requires_grad_(True)
+    cot = torch.randn(5, 24, generator=g).to(dev)
+    (gw_ref,) = torch.autograd.grad((GF.DemodFn.apply(sg, w) * cot).sum(), [w])
+    w.grad = torch.full_like(w, 0.25)
+    with GF.direct_param_grads():
+        (GF.DemodFn.apply(sg, w) * cot).sum().backward()
+    assert rel_err(w.grad, gw_ref + 0.25) < 1e-6 and sg.grad is not None
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
