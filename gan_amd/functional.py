@@ -461,7 +461,19 @@ def pack_weight(weight: Tensor, dtype: torch.dtype, cin_mult: int = 8, transpose
     `transposed` packs the flipped, channel-swapped weights of the input-gradient correlation."""
     cacheable = weight.is_leaf and (weight.requires_grad or isinstance(weight, torch.nn.Parameter)) and weight.numel() > 0
     if not cacheable:
-        return _pack_weight(weight.detach(), dtype, cin_mult, transposed)
+        owner = _fold_owner(weight) if _FOLD_OWNER else None
+        if owner is None:
+            return _pack_weight(weight.detach(), dtype, cin_mult, transposed)
+        key = ("fold", id(owner), dtype, cin_mult, transposed)  # images of a parameter's folded copy: valid as long as the copy is
+        ver = (owner._version, owner.data_ptr())
+        hit = _PACK_CACHE.get(key)
+        if hit is not None and hit[0]() is owner and hit[1] == ver:
+            PACK_STATS[0] += 1
+            return hit[2]
+        PACK_STATS[1] += 1
+        packed = _pack_weight(weight.detach(), dtype, cin_mult, transposed)
+        _PACK_CACHE[key] = (weakref.ref(owner), ver, packed)
+        return packed
     key = (id(weight), dtype, cin_mult, transposed)
     hit = _PACK_CACHE.get(key)
     if hit is not None and hit[0]() is weight and hit[1] == (weight._version, weight.data_ptr()):
@@ -497,6 +509,8 @@ def drop_packed() -> None:
     without bumping their versions; buffers recorded during an aborted capture were never written)."""
     _PACK_CACHE.clear()
     _WSQ_CACHE.clear()
+    _FOLD_CACHE.clear()
+    _FOLD_OWNER.clear()
     _PAD_MEMO.clear()
 
 
@@ -505,10 +519,13 @@ def invalidate_packed(params) -> None:
     back -- through a flat arena or a raw pointer (EMA.step, a graph replay) -- so that neither `_version` nor
     `data_ptr()` moves and the cache key above would still match."""
     ids = {id(p) for p in params}
-    for key in [k for k in _PACK_CACHE if k[0] in ids]:
+    for key in [k for k in _PACK_CACHE if (k[1] if k[0] == "fold" else k[0]) in ids]:
         del _PACK_CACHE[key]
     for i in ids:
         _WSQ_CACHE.pop(i, None)
+        hit = _FOLD_CACHE.pop(i, None)
+        if hit is not None:
+            _FOLD_OWNER.pop(hit[2].data_ptr(), None)
 
 
 # ---- all packed images of a network in one launch -----------------------------------------------------------
@@ -1678,6 +1695,64 @@ class DepthToSpaceFn(Function):
     @staticmethod
     def backward(ctx, g):
         return SpaceToDepthFn.apply(g, ctx.pad), None, None, None
+
+
+# (Co, C, 2m, 2m) stride-2 kernels as stride-1 kernels over space-to-depth input, once per version of the parameter
+_FOLD_CACHE: dict = {}   # id(param) -> (weakref, (version, data_ptr), folded tensor)
+_FOLD_OWNER: dict = {}   # data_ptr of a cached folded tensor -> weakref(param): lets pack_weight cache its GEMM images
+
+
+def _fold_perm(w: Tensor) -> Tensor:
+    co, c, k, _ = w.shape
+    m = k // 2
+    return w.reshape(co, c, m, 2, m, 2).permute(0, 3, 5, 1, 2, 4).reshape(co, 4 * c, m, m)
+
+
+def _unfold_perm(g: Tensor) -> Tensor:
+    co, c4, m, _ = g.shape
+    c = c4 // 4
+    return g.reshape(co, 2, 2, c, m, m).permute(0, 3, 4, 1, 5, 2).reshape(co, c, 2 * m, 2 * m)
+
+
+class FoldWeightFn(Function):
+    """(Co, C, 2m, 2m) -> (Co, 4C, m, m): input channel (dy*2+dx)*C + c, tap (by, bx) <- tap (2by+dy, 2bx+dx): the stride-2
+    kernel of Conv2d / ConvTranspose2d (dcgan.py:21-29,53-61) as a stride-1 kernel over space-to-depth input.  A permutation
+    of the parameter.  The folded copy of a PARAMETER is kept until its version moves (a WGAN-GP discriminator step used
+    each weight ~8 times: 8 permute copies and 8 uncached packs), and pack_weight caches the GEMM images of that copy."""
+
+    @staticmethod
+    def forward(ctx, weight):
+        if not (isinstance(weight, torch.nn.Parameter) and weight.is_leaf):
+            return _fold_perm(weight.detach()).contiguous()
+        ver = (weight._version, weight.data_ptr())
+        hit = _FOLD_CACHE.get(id(weight))
+        if hit is not None and hit[0]() is weight and hit[1] == ver:
+            return hit[2].detach()  # a new alias per call: autograd writes its graph node on the tensor it is handed
+        if len(_FOLD_CACHE) > 1024:
+            _FOLD_CACHE.clear()
+            _FOLD_OWNER.clear()
+        if hit is not None:
+            _FOLD_OWNER.pop(hit[2].data_ptr(), None)
+        folded = _fold_perm(weight.detach()).contiguous()
+        _FOLD_CACHE[id(weight)] = (weakref.ref(weight), ver, folded)
+        _FOLD_OWNER[folded.data_ptr()] = weakref.ref(weight)
+        return folded.detach()
+
+    @staticmethod
+    def backward(ctx, g):
+        return _unfold_perm(g)
+
+
+def _fold_owner(t: Tensor):
+    """The parameter whose current cached folded copy `t` aliases, or None."""
+    ref = _FOLD_OWNER.get(t.data_ptr())
+    p = ref() if ref is not None else None
+    if p is None:
+        return None
+    hit = _FOLD_CACHE.get(id(p))
+    if hit is None or hit[0]() is not p or hit[1] != (p._version, p.data_ptr()) or hit[2].data_ptr() != t.data_ptr() or hit[2].shape != t.shape:
+        return None
+    return p
 
 
 class InstNormAffineFn(Function):

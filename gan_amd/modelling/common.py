@@ -113,10 +113,9 @@ def get_act(act: str):
 
 def _fold_weight(weight: Tensor) -> Tensor:
     """(Co, C, 2m, 2m) -> (Co, 4C, m, m): the stride-2 kernel as a stride-1 kernel over space-to-depth input, input channel
-    (dy*2+dx)*C + c and tap (by, bx) <- tap (2by+dy, 2bx+dx).  A permutation of the parameter (differentiable view + copy)."""
-    co, c, k, _ = weight.shape
-    m = k // 2
-    return weight.reshape(co, c, m, 2, m, 2).permute(0, 3, 5, 1, 2, 4).reshape(co, 4 * c, m, m)
+    (dy*2+dx)*C + c and tap (by, bx) <- tap (2by+dy, 2bx+dx).  A permutation of the parameter, kept per parameter version
+    (functional.FoldWeightFn)."""
+    return GF.FoldWeightFn.apply(weight)
 
 
 class _StridedConv2d(nn.Conv2d):
