@@ -46,6 +46,8 @@ _SIGNATURES = {
     ),
     "gan_conv2d_wgrad_workspace": (c_int64, [c_int] * 13),
     "gan_conv2d_wgrad": (c_int, [c_void_p] * 3 + [c_int, c_int, c_void_p] + [c_int] * 12 + [c_void_p, c_int64, c_float, c_int, c_float, c_int, c_int, c_void_p]),
+    "gan_conv2d_wgrad_bias_workspace": (c_int64, [c_int] * 14),
+    "gan_conv2d_wgrad_bias": (c_int, [c_void_p] * 3 + [c_int, c_int, c_void_p, c_int, c_void_p] + [c_int] * 12 + [c_void_p, c_int64, c_float, c_int, c_float, c_int, c_int, c_void_p]),
     "gan_amd_init": (c_int, []),
     "gan_conv2d_wgrad_static_max_floats": (c_int64, []),
     "gan_conv2d_wgrad_static": (c_int, [c_void_p] * 3 + [c_int, c_int, c_void_p] + [c_int] * 12 + [c_float, c_int, c_float, c_int, c_void_p]),

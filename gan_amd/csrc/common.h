@@ -170,6 +170,10 @@ struct DwOut {
     float* out;
     int cout, cin;
     int accumulate;  // 1: dw += result (the caller's gradient buffer), 0: dw = result
+    // the bias gradient of the same layer, sum over (n, oy, ox) of gy (cout floats), or nullptr: a by-product of the
+    // thin kernel (one more MFMA per tile row against a fragment of ones); other paths run the channel-sum kernel
+    float* bias;
+    int bias_accumulate;
 };
 
 // conv_thin_wgrad.hip: weight gradient for thin layers (bf16, needs the workspace it reports through `need`).
@@ -182,7 +186,9 @@ int64_t gan_wgrad_tiled_workspace(int N, int Ho, int Wo, int Cin, int Cout, int 
 int gan_conv2d_wgrad_tiled(const void* x, const void* gy, const DwOut& dwo, const float* in_scale, int N, int H, int W,
                            int Cin, int up2, int Ho, int Wo, int Cout, int kh, int kw, int py, int px, float* ws,
                            int64_t ws_floats, const WgradFuse& fu, hipStream_t st);
-int gan_finalize_dw(const float* ws, int S, int taps, int Cout, int Cin, const DwOut& dwo, float gain, hipStream_t st);
+// bias_plane != 0: every slice is followed by Cout channel sums (slice stride taps*Cout*Cin + Cout), folded into dwo.bias
+int gan_finalize_dw(const float* ws, int S, int taps, int Cout, int Cin, const DwOut& dwo, float gain, hipStream_t st, int bias_plane = 0,
+                    float bias_gain = 1.f);
 
 // upfirdn_mfma.hip: bf16 upfirdn2d with the FIR as banded matrix products on MFMA.  1 / 0 / < 0 as above.
 int gan_upfirdn2d_mfma(const void* x, const float* taps, void* y, int N, int H, int W, int C, int ky, int kx, int up,

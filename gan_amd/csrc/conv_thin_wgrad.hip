@@ -30,6 +30,7 @@ struct ThinWArgs {
     unsigned x_bytes, g_bytes;  // < 2^31: 32-bit buffer offsets
     WgradFuse fu;
     DwOut dwo;  // host side only: where the slice reducer writes
+    int want_bias;  // also sum gy over the pixels: Cout floats behind every slice (slice stride taps*Cout*Cin + Cout)
 };
 
 __device__ __forceinline__ uint4 wmod_chunk(uint4 raw, const float* s) {
@@ -103,6 +104,15 @@ __global__ void __launch_bounds__(256, 2) conv_thin_wgrad_k(const ThinWArgs p) {
 
     const int g = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
     const int lane_off = (4 * g + q) * 32 + pp * 8;  // this lane's piece inside a 32-pixel run
+    // bias gradient: sum_pixels gy[co] = gy^T x ones, one more MFMA per tile row on the waves of tap group 0 (every
+    // column of the result tile holds the sum); no VALU, no second pass over gy
+    f32x4 accb[CGO];
+#pragma unroll
+    for (int o = 0; o < CGO; ++o) accb[o] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
+    const bool sum_gy = p.want_bias && wt == 0;
 
     for (int t = t0; t < t1; ++t) {
         const int n = t / tiles_per_img;
@@ -195,6 +205,10 @@ __global__ void __launch_bounds__(256, 2) conv_thin_wgrad_k(const ThinWArgs p) {
             bf16x8 a[CGO];
 #pragma unroll
             for (int o = 0; o < CGO; ++o) a[o] = tr_frag(gl + o * PLG + r * 32 * 32 + lane_off);
+            if (sum_gy) {
+#pragma unroll
+                for (int o = 0; o < CGO; ++o) accb[o] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[o], ones, accb[o], 0, 0, 0);
+            }
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 const int tap = wt + j * WT;
@@ -246,9 +260,26 @@ __global__ void __launch_bounds__(256, 2) conv_thin_wgrad_k(const ThinWArgs p) {
                 }
             }
         }
+        const int64_t L = (int64_t)KS * KS * p.Cout * p.Cin;
+        const int64_t Lp = L + (p.want_bias ? p.Cout : 0);
+        if (p.want_bias) {
+            __syncthreads();  // the fold's LDS reads are done
+            float* const bs = reinterpret_cast<float*>(lds);  // [WR][COUT] row-group partials
+            if (wt == 0 && li == 0) {
+#pragma unroll
+                for (int o = 0; o < CGO; ++o)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) bs[wr * COUT + o * 16 + g * 4 + r] = accb[o][r];
+            }
+            __syncthreads();
+            if (tid < p.Cout) {
+                float sum = 0.f;
+                for (int w = 0; w < C::WR; ++w) sum += bs[w * COUT + tid];
+                p.ws[(int64_t)blockIdx.x * Lp + L + tid] = sum;
+            }
+        }
         if (wr == 0) {
-            const int64_t L = (int64_t)KS * KS * p.Cout * p.Cin;
-            float* __restrict__ base = p.ws + (int64_t)blockIdx.x * L;
+            float* __restrict__ base = p.ws + (int64_t)blockIdx.x * Lp;
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 const int tap = wt + j * WT;
@@ -287,7 +318,7 @@ int launch_thin_w(ThinWArgs a, int64_t ws_floats, int64_t* need, hipStream_t st)
     int64_t grid = 256LL * per_cu;
     if (grid > ntiles) grid = ntiles;
     const int64_t L = (int64_t)KS * KS * a.Cout * a.Cin;
-    const int64_t want = grid * L;
+    const int64_t want = grid * (L + a.Cout);  // (room for the channel sums whether or not this call wants them)
     if (need) {
         *need = want;
         return GAN_OK;
@@ -295,7 +326,8 @@ int launch_thin_w(ThinWArgs a, int64_t ws_floats, int64_t* need, hipStream_t st)
     if (a.ws == nullptr || ws_floats < want) return 1;  // not served without its slices (GAN_OK is 0; the caller maps 1 -> 0)
     hipLaunchKernelGGL((conv_thin_wgrad_k<CIN, COUT, KS, TH, WT>), dim3((unsigned)grid), dim3(256), 0, st, a);
     GAN_CHECK_LAUNCH("conv2d_wgrad(thin)");
-    return gan_finalize_dw(a.ws, (int)grid, KS * KS, a.Cout, a.Cin, a.dwo, a.fu.gain, st);
+    // (gy at half resolution is staged four times per source pixel: the sums come out 4x)
+    return gan_finalize_dw(a.ws, (int)grid, KS * KS, a.Cout, a.Cin, a.dwo, a.fu.gain, st, a.want_bias, a.fu.gy_up2 ? 0.25f : 1.f);
 }
 
 template <int CIN, int COUT>
@@ -332,6 +364,7 @@ int gan_conv2d_wgrad_thin(const void* x, const void* gy, const DwOut& dwo, const
     a.x_bytes = (unsigned)xb; a.g_bytes = (unsigned)gb;
     a.fu = fu;
     a.x = x; a.gy = gy; a.dw = nullptr; a.dwo = dwo; a.in_scale = in_scale;
+    a.want_bias = dwo.bias != nullptr;
     a.N = N; a.H = H; a.W = W; a.Hl = up2 ? 2 * H : H; a.Wl = up2 ? 2 * W : W; a.up2 = up2;
     a.Ho = Ho; a.Wo = Wo; a.Cin = Cin; a.Cout = Cout; a.py = py; a.px = px;
     a.tiles_x = a.tiles_y = 0;

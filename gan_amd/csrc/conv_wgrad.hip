@@ -241,16 +241,20 @@ extern "C" int64_t gan_conv2d_wgrad_workspace(int N, int H, int W, int Cin, int 
     const int64_t L = (int64_t)kh * kw * Cout * Cin;  // every path folds at least one padded slice into dw
     if (dtype != GAN_BF16) return L;
     int64_t need = 0;
-    gan_conv2d_wgrad_thin(nullptr, nullptr, DwOut{nullptr, 0, 0, 0}, nullptr, N, H, W, Cin, up2, Ho, Wo, Cout, kh, kw, py, px, nullptr, 0,
+    gan_conv2d_wgrad_thin(nullptr, nullptr, DwOut{nullptr, 0, 0, 0, nullptr, 0}, nullptr, N, H, W, Cin, up2, Ho, Wo, Cout, kh, kw, py, px, nullptr, 0,
                           &need, WgradFuse{1.f, 0, 1.f}, nullptr);
     if (need == 0) need = gan_wgrad_tiled_workspace(N, Ho, Wo, Cin, Cout, kh, kw, py, px);
     return need > L ? need : L;
 }
 
+extern "C" int gan_chan_dot(const void* A, const void* B, int b_mode, const void* ymask, float slope, float* out, int64_t out_stride_n, int N,
+                            int64_t HW, int C, float* workspace, int64_t workspace_floats, int accumulate, int dtype, gan_stream_t stream);
+extern "C" int64_t gan_chan_dot_workspace(int N, int64_t HW, int C, int dtype);
+
 static int wgrad_impl(const void* x, const void* gy, float* dw, int Cout_out, int Cin_out, const float* in_scale, int N,
                       int H, int W, int Cin, int up2, int Ho, int Wo, int Cout, int kh, int kw, int py, int px,
                       float* workspace, int64_t workspace_floats, float x_slope, int gy_up2, float gain, int accumulate,
-                      int dtype, gan_stream_t stream) {
+                      int dtype, gan_stream_t stream, float* dbias = nullptr, int dbias_accumulate = 0) {
     GAN_CHECK_ARG(dw && (N == 0 || (x && gy)), "conv2d_wgrad: null pointer");
     GAN_CHECK_ARG(accumulate == 0 || accumulate == 1, "conv2d_wgrad: accumulate must be 0 or 1");
     GAN_CHECK_ARG(dtype == GAN_F32 || dtype == GAN_BF16, "conv2d_wgrad: bad dtype %d", dtype);
@@ -268,10 +272,23 @@ static int wgrad_impl(const void* x, const void* gy, float* dw, int Cout_out, in
     GAN_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)gy % 16) == 0, "conv2d_wgrad: x and gy must be 16-byte aligned");
     GAN_CHECK_ARG(gy_up2 == 0 || (gy_up2 == 1 && Ho % 2 == 0 && Wo % 2 == 0), "conv2d_wgrad: gy_up2 needs an even %dx%d output", Ho, Wo);
     const WgradFuse fu{x_slope, gy_up2, gain};
-    const DwOut dwo{dw, Cout_out, Cin_out, accumulate};
+    GAN_CHECK_ARG(dbias == nullptr || Cout_out == Cout, "conv2d_wgrad_bias: the bias gradient needs an unpadded Cout (%d of %d)", Cout_out, Cout);
+    GAN_CHECK_ARG(dbias_accumulate == 0 || dbias_accumulate == 1, "conv2d_wgrad_bias: dbias_accumulate must be 0 or 1");
+    DwOut dwo{dw, Cout_out, Cin_out, accumulate, dbias, dbias_accumulate};
     hipStream_t st = (hipStream_t)stream;
     const int64_t L = (int64_t)kh * kw * Cout * Cin;
+    // the bias gradient on the paths whose kernels do not produce it: the channel-sum kernel over gy (after the weight
+    // gradient: it reuses the workspace)
+    const int64_t HWg = (int64_t)(Ho >> gy_up2) * (Wo >> gy_up2);
+    auto bias_by_sum = [&]() -> int {
+        if (!dbias) return GAN_OK;
+        return gan_chan_dot(gy, nullptr, 0, nullptr, 1.f, dbias, 0, N, HWg, Cout, workspace, workspace_floats, dbias_accumulate, dtype, stream);
+    };
     if (N == 0) {
+        if (dbias && !dbias_accumulate && hipMemsetAsync(dbias, 0, sizeof(float) * (size_t)Cout, st) != hipSuccess) {
+            gan_set_error("conv2d_wgrad: memset failed");
+            return GAN_ERR_LAUNCH;
+        }
         if (accumulate) return GAN_OK;
         if (hipMemsetAsync(dw, 0, sizeof(float) * (size_t)kh * kw * Cout_out * Cin_out, st) != hipSuccess) {
             gan_set_error("conv2d_wgrad: memset failed");
@@ -279,18 +296,24 @@ static int wgrad_impl(const void* x, const void* gy, float* dw, int Cout_out, in
         }
         return GAN_OK;
     }
-    const int64_t need = gan_conv2d_wgrad_workspace(N, H, W, Cin, up2, Ho, Wo, Cout, kh, kw, py, px, dtype);
+    int64_t need = gan_conv2d_wgrad_workspace(N, H, W, Cin, up2, Ho, Wo, Cout, kh, kw, py, px, dtype);
+    if (dbias) {
+        const int64_t nb = gan_chan_dot_workspace(N, HWg, Cout, dtype);
+        if (nb > need) need = nb;
+    }
     GAN_CHECK_ARG(workspace != nullptr && workspace_floats >= need && ((uintptr_t)workspace % 16) == 0,
                   "conv2d_wgrad: needs a 16-byte aligned workspace of %lld floats (gan_conv2d_wgrad_workspace), got %lld",
                   (long long)need, (long long)workspace_floats);
     if (dtype == GAN_BF16) {
         int rc = gan_conv2d_wgrad_thin(x, gy, dwo, in_scale, N, H, W, Cin, up2, Ho, Wo, Cout, kh, kw, py, px, workspace,
                                        workspace_floats, nullptr, fu, st);
-        if (rc != 0) return rc < 0 ? rc : GAN_OK;
+        if (rc != 0) return rc < 0 ? rc : GAN_OK;  // (the thin kernel sums gy on the way: dwo.bias)
+        dwo.bias = nullptr;
         rc = gan_conv2d_wgrad_tiled(x, gy, dwo, in_scale, N, H, W, Cin, up2, Ho, Wo, Cout, kh, kw, py, px, workspace,
                                     workspace_floats, fu, st);
-        if (rc != 0) return rc < 0 ? rc : GAN_OK;
+        if (rc != 0) return rc < 0 ? rc : bias_by_sum();
     }
+    dwo.bias = nullptr;
     // register-staged kernel: fp32 atomics into one zeroed, padded slice of the workspace, then the same reducer
     if (hipMemsetAsync(workspace, 0, sizeof(float) * (size_t)L, st) != hipSuccess) {
         gan_set_error("conv2d_wgrad: memset failed");
@@ -306,7 +329,8 @@ static int wgrad_impl(const void* x, const void* gy, float* dw, int Cout_out, in
     a.pix_per_split = 128;
     const int rc = dtype == GAN_F32 ? launch<float>(a, st) : launch<bf16>(a, st);
     if (rc != GAN_OK) return rc;
-    return gan_finalize_dw(workspace, 1, kh * kw, Cout, Cin, dwo, 1.f, st);  // the kernel applied the gain
+    const int rf = gan_finalize_dw(workspace, 1, kh * kw, Cout, Cin, dwo, 1.f, st);  // the kernel applied the gain
+    return rf != GAN_OK ? rf : bias_by_sum();
 }
 
 extern "C" int gan_conv2d_wgrad(const void* x, const void* gy, float* dw, int Cout_out, int Cin_out, const float* in_scale, int N,
@@ -315,6 +339,22 @@ extern "C" int gan_conv2d_wgrad(const void* x, const void* gy, float* dw, int Co
                                 int dtype, gan_stream_t stream) {
     return wgrad_impl(x, gy, dw, Cout_out, Cin_out, in_scale, N, H, W, Cin, up2, Ho, Wo, Cout, kh, kw, py, px, workspace,
                       workspace_floats, x_slope, gy_up2, gain, accumulate, dtype, stream);
+}
+
+extern "C" int64_t gan_conv2d_wgrad_bias_workspace(int N, int H, int W, int Cin, int up2, int Ho, int Wo, int Cout, int kh, int kw, int py,
+                                                   int px, int gy_up2, int dtype) {
+    const int64_t a = gan_conv2d_wgrad_workspace(N, H, W, Cin, up2, Ho, Wo, Cout, kh, kw, py, px, dtype);
+    const int64_t b = gan_chan_dot_workspace(N, (int64_t)(Ho >> (gy_up2 ? 1 : 0)) * (Wo >> (gy_up2 ? 1 : 0)), Cout, dtype);
+    return a > b ? a : b;
+}
+
+extern "C" int gan_conv2d_wgrad_bias(const void* x, const void* gy, float* dw, int Cout_out, int Cin_out, float* dbias, int dbias_accumulate,
+                                     const float* in_scale, int N, int H, int W, int Cin, int up2, int Ho, int Wo, int Cout, int kh, int kw,
+                                     int py, int px, float* workspace, int64_t workspace_floats, float x_slope, int gy_up2, float gain,
+                                     int accumulate, int dtype, gan_stream_t stream) {
+    GAN_CHECK_ARG(dbias != nullptr, "conv2d_wgrad_bias: null dbias (gan_conv2d_wgrad computes the weight gradient alone)");
+    return wgrad_impl(x, gy, dw, Cout_out, Cin_out, in_scale, N, H, W, Cin, up2, Ho, Wo, Cout, kh, kw, py, px, workspace,
+                      workspace_floats, x_slope, gy_up2, gain, accumulate, dtype, stream, dbias, dbias_accumulate);
 }
 
 // ---- the entry point that allocates nothing (include/gan_amd.h: gan_conv2d_wgrad_static) ------------------------

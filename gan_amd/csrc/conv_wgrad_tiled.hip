@@ -280,18 +280,19 @@ __global__ void __launch_bounds__(TW_THREADS) conv_wgrad_tiled_k(const TWArgs p)
 // layout (cout x cin x taps, channel padding dropped), so the caller needs neither a zeroed target nor a
 // permute / slice copy afterwards.  A block owns 64 quads of consecutive ci; its SG waves split the slices.
 template <int SG>
-__global__ void __launch_bounds__(64 * SG) finalize_dw_k(const float* __restrict__ ws, float* __restrict__ out, int64_t L, int S,
-                                                         int taps, int Cout, int Cin, int cout_o, int cin_o, float gain, int accum) {
+__global__ void __launch_bounds__(64 * SG) finalize_dw_k(const float* __restrict__ ws, float* __restrict__ out, int64_t L, int64_t Lp, int S,
+                                                         int taps, int Cout, int Cin, int cout_o, int cin_o, float gain, int accum,
+                                                         float* __restrict__ bias, float bias_gain, int bias_accum) {
     __shared__ float4 part[SG * 64];
     const int lane = threadIdx.x & 63, sg = threadIdx.x >> 6;
     const int64_t e4 = (int64_t)blockIdx.x * 64 + lane;
-    const bool live = e4 * 4 < L;
+    const bool live = e4 * 4 < Lp;
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
     if (live) {
         const float* __restrict__ src = ws + e4 * 4;
 #pragma unroll 8
         for (int s = sg; s < S; s += SG) {
-            const float4 v = *reinterpret_cast<const float4*>(src + (int64_t)s * L);
+            const float4 v = *reinterpret_cast<const float4*>(src + (int64_t)s * Lp);
             a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
         }
     }
@@ -308,6 +309,14 @@ __global__ void __launch_bounds__(64 * SG) finalize_dw_k(const float* __restrict
     }
     if (sg != 0 || !live) return;
     const int64_t idx = e4 * 4;
+    if (idx >= L) {  // the channel sums behind the slice: the bias gradient
+        const int c = (int)(idx - L);
+        const float r[4] = {a.x * bias_gain, a.y * bias_gain, a.z * bias_gain, a.w * bias_gain};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (bias && c + j < cout_o) bias[c + j] = bias_accum ? bias[c + j] + r[j] : r[j];
+        return;
+    }
     const int plane = Cout * Cin;
     const int tap = (int)(idx / plane);
     const int rem = (int)(idx - (int64_t)tap * plane);
@@ -421,19 +430,23 @@ int gan_conv2d_wgrad_tiled(const void* x, const void* gy, const DwOut& dwo, cons
     return rc == GAN_OK ? 1 : rc;
 }
 
-int gan_finalize_dw(const float* ws, int S, int taps, int Cout, int Cin, const DwOut& dwo, float gain, hipStream_t st) {
+int gan_finalize_dw(const float* ws, int S, int taps, int Cout, int Cin, const DwOut& dwo, float gain, hipStream_t st, int bias_plane,
+                    float bias_gain) {
     const int64_t L = (int64_t)taps * Cout * Cin;
-    if ((Cin & 3) || S < 1 || dwo.cout > Cout || dwo.cin > Cin) {
+    if ((Cin & 3) || S < 1 || dwo.cout > Cout || dwo.cin > Cin || (bias_plane && (Cout & 3))) {
         gan_set_error("finalize_dw: bad shape (Cin %d must be a multiple of 4, S %d >= 1)", Cin, S);
         return GAN_ERR_ARG;
     }
-    const unsigned blocks = (unsigned)ceil_div64(ceil_div64(L, 4), 64);
+    const int64_t Lp = L + (bias_plane ? Cout : 0);
+    const unsigned blocks = (unsigned)ceil_div64(ceil_div64(Lp, 4), 64);
+#define FIN_ARGS ws, dwo.out, L, Lp, S, taps, Cout, Cin, dwo.cout, dwo.cin, gain, dwo.accumulate, dwo.bias, bias_gain, dwo.bias_accumulate
     if (S <= 8)
-        hipLaunchKernelGGL(finalize_dw_k<1>, dim3(blocks), dim3(64), 0, st, ws, dwo.out, L, S, taps, Cout, Cin, dwo.cout, dwo.cin, gain, dwo.accumulate);
+        hipLaunchKernelGGL(finalize_dw_k<1>, dim3(blocks), dim3(64), 0, st, FIN_ARGS);
     else if (S <= 64)
-        hipLaunchKernelGGL(finalize_dw_k<4>, dim3(blocks), dim3(256), 0, st, ws, dwo.out, L, S, taps, Cout, Cin, dwo.cout, dwo.cin, gain, dwo.accumulate);
+        hipLaunchKernelGGL(finalize_dw_k<4>, dim3(blocks), dim3(256), 0, st, FIN_ARGS);
     else
-        hipLaunchKernelGGL(finalize_dw_k<16>, dim3(blocks), dim3(1024), 0, st, ws, dwo.out, L, S, taps, Cout, Cin, dwo.cout, dwo.cin, gain, dwo.accumulate);
+        hipLaunchKernelGGL(finalize_dw_k<16>, dim3(blocks), dim3(1024), 0, st, FIN_ARGS);
+#undef FIN_ARGS
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         gan_set_error("finalize_dw: launch failed: %s", hipGetErrorString(e));

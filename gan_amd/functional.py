@@ -795,10 +795,12 @@ def raw_conv2d_dgrad(
 
 def raw_conv2d_wgrad(
     x: Tensor, gy: Tensor, kh: int, kw: int, py: int, px: int, *, up2: bool = False, in_scale: Optional[Tensor] = None,
-    x_slope: float = 1.0, pooled: bool = False, into: Optional[Tensor] = None,
-) -> Tensor:
+    x_slope: float = 1.0, pooled: bool = False, into: Optional[Tensor] = None, bias: bool = False, bias_into: Optional[Tensor] = None,
+):
     """fp32 (Cout, Cin, kh, kw).  x_slope: x goes through leaky-ReLU first; pooled: gy is the gradient of the
-    2x2-average-pooled output (half resolution); into: an fp32 (Cout, Cin, kh, kw) buffer the gradient is ADDED to."""
+    2x2-average-pooled output (half resolution); into: an fp32 (Cout, Cin, kh, kw) buffer the gradient is ADDED to.
+    bias: also the layer's bias gradient, sum of gy over (n, y, x), from the same call (gan_conv2d_wgrad_bias; Cout a
+    multiple of 16) -> returns (dw, dbias); bias_into: an fp32 (Cout,) buffer it is ADDED to."""
     require_gpu(x, gy, in_scale)
     lib = _lib.load()
     cin, cout = x.shape[1], gy.shape[1]
@@ -816,12 +818,33 @@ def raw_conv2d_wgrad(
     if into is not None:
         assert into.dtype == torch.float32 and into.is_contiguous() and tuple(into.shape) == (cout, cin, kh, kw)
     dw = into if into is not None else torch.empty((cout, cin, kh, kw), dtype=torch.float32, device=x.device)
+    thin_w = (x.dtype == torch.bfloat16 and kh == kw and kh in (1, 3) and py == px == (kh - 1) // 2 and cin_p <= 64
+              and cout_p <= 64 and wo >= 32 and ho >= 8)
+    if bias:
+        if cout_p != cout:
+            raise _lib.GanAmdError(f"conv2d_wgrad: the fused bias gradient needs Cout % 16 == 0, got {cout}")
+        if bias_into is not None:
+            assert bias_into.dtype == torch.float32 and bias_into.is_contiguous() and bias_into.numel() == cout
+        db = bias_into if bias_into is not None else torch.empty((cout,), dtype=torch.float32, device=x.device)
+        ws_floats = lib.gan_conv2d_wgrad_bias_workspace(n, h, w, cin_p, int(up2), ho, wo, cout_p, kh, kw, py, px, int(pooled), dtype_code(x))
+        ws = torch.empty((max(ws_floats, 1),), dtype=torch.float32, device=x.device)
+        check(
+            _run(
+                "conv2d_wgrad_thin" if thin_w else "conv2d_wgrad", 2.0 * n * ho * wo * cout * cin * kh * kw, _nbytes(x, gy, dw),
+                lambda: lib.gan_conv2d_wgrad_bias(
+                    ptr(x), ptr(gy), ptr(dw), cout, cin, ptr(db), int(bias_into is not None), ptr(in_scale), n, h, w, cin_p, int(up2), ho, wo,
+                    cout_p, kh, kw, py, px, ptr(ws), ws_floats, float(x_slope), int(pooled), 0.25 if pooled else 1.0, int(into is not None),
+                    dtype_code(x), stream_of(x)
+                ),
+                (n, cin, ho, wo, cout, kh, int(up2), int(pooled)),
+            ),
+            "gan_conv2d_wgrad_bias",
+        )
+        return dw, db
     # split-K partials go to a caller-owned workspace (the library never allocates); torch's caching
     # allocator hands the same block back every step.  The slice reducer writes dw in the parameter's layout.
     ws_floats = lib.gan_conv2d_wgrad_workspace(n, h, w, cin_p, int(up2), ho, wo, cout_p, kh, kw, py, px, dtype_code(x))
     ws = torch.empty((ws_floats,), dtype=torch.float32, device=x.device) if ws_floats > 0 else None
-    thin_w = (x.dtype == torch.bfloat16 and kh == kw and kh in (1, 3) and py == px == (kh - 1) // 2 and cin_p <= 64
-              and cout_p <= 64 and wo >= 32 and ho >= 8)
     check(
         _run(
             "conv2d_wgrad_thin" if thin_w else "conv2d_wgrad", 2.0 * n * ho * wo * cout * cin * kh * kw, _nbytes(x, gy, dw),
@@ -910,6 +933,20 @@ def _bias_grad_for(b: Tensor, g: Tensor) -> Optional[Tensor]:
     if isinstance(b, torch.nn.Parameter):
         b._gan_direct = True  # FlatArena.begin_direct: give this parameter a zeroed gradient slice from the next pass on
     return ChanSumFn.apply(g, False).reshape(b.shape).to(b.dtype)
+
+
+def _wgrad_and_bias_for(w: Tensor, b: Tensor, x: Tensor, gy: Tensor, py: int, px: int, x_slope: float = 1.0, pool: bool = False):
+    """(gradient of conv weight w, gradient of its bias b) from the same gy.  In a backward pass that is not recorded both
+    come from ONE call (gan_conv2d_wgrad_bias: on thin layers the kernel sums gy with one more MFMA per tile row, so the
+    channel-sum pass over gy -- a full read of the largest tensors of the discriminator's backward -- disappears); each is
+    None when it was added into the parameter's .grad (grad_slot)."""
+    if torch.is_grad_enabled() or gy.shape[1] % 16 != 0 or b.numel() != gy.shape[1] or not gy.is_cuda:
+        return _wgrad_for(w, x, gy, py, px, x_slope, pool), _bias_grad_for(b, gy)
+    wslot, bslot = grad_slot(w), grad_slot(b)
+    if isinstance(b, torch.nn.Parameter):
+        b._gan_direct = True
+    dw, db = raw_conv2d_wgrad(x, gy, w.shape[2], w.shape[3], py, px, x_slope=x_slope, pooled=pool, into=wslot, bias=True, bias_into=bslot)
+    return (None if wslot is not None else dw.to(w.dtype)), (None if bslot is not None else db.reshape(b.shape).to(b.dtype))
 
 
 class UpFirDnFn(Function):
@@ -1128,23 +1165,28 @@ class DBlockInputFn(Function):
         x, w1, b1, ws, xs = ctx.saved_tensors
         pad, slope, pool_in_conv = ctx.cfg
         gx = gw1 = gb1 = gws = gbs = None
-        if ctx.bs is not None and _need(ctx, 6):
-            gbs = _bias_grad_for(ctx.bs, g_s)
         if _need(ctx, 0):
             if pool_in_conv:
                 gx_s = Conv2dDgradFn.apply(g_s, ws, 0, 0, None, 1.0, True)
             else:
                 gx_s = UpFirDnFn.apply(Conv2dDgradFn.apply(g_s, ws, 0, 0), _ones_taps(x, 0.25), 2, 1, 1, 0, 1, 0)
             gx = Conv2dDgradFn.apply(g_p1, w1, pad, pad, x, slope, False, gx_s)
-        if _need(ctx, 1):
-            gw1 = _wgrad_for(w1, x, g_p1, pad, pad, slope, False)
-        if b1 is not None and _need(ctx, 2):
-            gb1 = _bias_grad_for(b1, g_p1)
+        if _need(ctx, 1) and b1 is not None and _need(ctx, 2):
+            gw1, gb1 = _wgrad_and_bias_for(w1, b1, x, g_p1, pad, pad, slope, False)
+        else:
+            if _need(ctx, 1):
+                gw1 = _wgrad_for(w1, x, g_p1, pad, pad, slope, False)
+            if b1 is not None and _need(ctx, 2):
+                gb1 = _bias_grad_for(b1, g_p1)
+        want_bs = ctx.bs is not None and _need(ctx, 6)
         if _need(ctx, 3):
-            if pool_in_conv:
-                gws = _wgrad_for(ws, x, g_s, 0, 0, 1.0, True)
+            xs_in, pooled = (x, True) if pool_in_conv else (xs, False)
+            if want_bs:
+                gws, gbs = _wgrad_and_bias_for(ws, ctx.bs, xs_in, g_s, 0, 0, 1.0, pooled)
             else:
-                gws = _wgrad_for(ws, xs, g_s, 0, 0)
+                gws = _wgrad_for(ws, xs_in, g_s, 0, 0, 1.0, pooled)
+        elif want_bs:
+            gbs = _bias_grad_for(ctx.bs, g_s)
         return gx, gw1, gb1, gws, None, None, gbs
 
 
@@ -1414,12 +1456,14 @@ class ConvBiasActFn(Function):
         gz = MaskMulFn.apply(gy, y, slope) if slope != 1.0 else gy
         xaux = x if in_slope != 1.0 else None
         gx = Conv2dDgradFn.apply(gz, weight, pad, pad, xaux, in_slope, pool) if _need(ctx, 0) else None
-        gw = None
-        if _need(ctx, 1):
-            gw = _wgrad_for(weight, x, gz, pad, pad, in_slope, pool)
-        gb = None
-        if bias is not None and _need(ctx, 2):
-            gb = _bias_grad_for(bias, gz)
+        gw = gb = None
+        if _need(ctx, 1) and bias is not None and _need(ctx, 2):
+            gw, gb = _wgrad_and_bias_for(weight, bias, x, gz, pad, pad, in_slope, pool)
+        else:
+            if _need(ctx, 1):
+                gw = _wgrad_for(weight, x, gz, pad, pad, in_slope, pool)
+            if bias is not None and _need(ctx, 2):
+                gb = _bias_grad_for(bias, gz)
         return gx, gw, gb, None, None, None, None
 
 

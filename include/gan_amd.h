@@ -180,6 +180,17 @@ int gan_conv2d_wgrad(const void* x, const void* gy, float* dw, int Cout_out, int
                      int up2, int Ho, int Wo, int Cout, int kh, int kw, int py, int px, float* workspace,
                      int64_t workspace_floats, float x_slope, int gy_up2, float gain, int accumulate, int dtype,
                      gan_stream_t stream);
+/* The same with the layer's BIAS gradient from the same call: dbias[co] (+)= sum over (n, oy, ox) of gy (Cout floats;
+ * needs Cout_out == Cout; dbias_accumulate as accumulate).  Replaces the `.sum((0, 2, 3))` autograd runs for the bias of
+ * nn.Conv2d (progressive_gan.py:45-50) -- a second full read of gy.  On the thin kernel the sums are one more MFMA per
+ * tile row (gy^T x ones) and ride in the split-K slices; other paths run the channel-sum kernel after the weight
+ * gradient, in the same workspace: gan_conv2d_wgrad_bias_workspace(...) floats (>= gan_conv2d_wgrad_workspace). */
+int64_t gan_conv2d_wgrad_bias_workspace(int N, int H, int W, int Cin, int up2, int Ho, int Wo, int Cout, int kh, int kw, int py, int px,
+                                        int gy_up2, int dtype);
+int gan_conv2d_wgrad_bias(const void* x, const void* gy, float* dw, int Cout_out, int Cin_out, float* dbias, int dbias_accumulate,
+                          const float* in_scale, int N, int H, int W, int Cin, int up2, int Ho, int Wo, int Cout, int kh, int kw, int py,
+                          int px, float* workspace, int64_t workspace_floats, float x_slope, int gy_up2, float gain, int accumulate,
+                          int dtype, gan_stream_t stream);
 
 /* The same weight gradient for callers that cannot allocate (code under HIP graph capture, tight serving loops,
  * harnesses that forbid hipMalloc).  NO counterpart in the reference: the reference allocates freely through

@@ -146,17 +146,35 @@ def test_checkpoint_resume(tmp_path, monkeypatch):
         for _ in range(2):
             a.train_step(lambda: reals)
         a.save_checkpoint(str(tmp_path / "ck.pt"))
+        saved = torch.load(str(tmp_path / "ck.pt"), map_location=dev, weights_only=True)
         mark = state["n"]
         want = [a.train_step(lambda: reals) for _ in range(2)]
         b = make()
         b.load_checkpoint(str(tmp_path / "ck.pt"))
         assert b.step == 2 and b.gen_ema._count == 2
+
+        def flat(obj, prefix=""):
+            if isinstance(obj, dict):
+                for k, v in obj.items():
+                    yield from flat(v, f"{prefix}/{k}")
+            elif isinstance(obj, (list, tuple)):
+                for i, v in enumerate(obj):
+                    yield from flat(v, f"{prefix}/{i}")
+            else:
+                yield prefix, obj
+
+        restored = dict(flat(b.state_dict()))
+        for key, v in flat(saved):  # the restored trainer holds exactly what was saved, bit for bit
+            r = restored[key]
+            assert (torch.equal(r.cpu(), v.cpu()) if isinstance(v, torch.Tensor) else r == v), key
         state["n"] = mark
         got = [b.train_step(lambda: reals) for _ in range(2)]
     finally:
         monkeypatch.setattr(torch, "randn", real_randn)
+    # the continued run tracks the one that never stopped; not bit for bit: the fp32 weight-gradient kernel adds its split-K
+    # partials with atomics, and hinge + R1 + Adam(beta1 = 0) amplifies the last bit (1e-3 after four steps)
     for w_, g_ in zip(want, got):
         for k in ("loss/d", "loss/g"):
-            assert abs(float(w_[k]) - float(g_[k])) <= 1e-4 * max(1.0, abs(float(w_[k]))), (k, float(w_[k]), float(g_[k]))
+            assert abs(float(w_[k]) - float(g_[k])) <= 1e-3 * max(1.0, abs(float(w_[k]))), (k, float(w_[k]), float(g_[k]))
     for p, q in zip(a.gen.parameters(), b.gen.parameters()):
-        assert torch.allclose(p, q, atol=1e-5)
+        assert (p - q).abs().max() < 1e-4  # (one Adam step moves a weight by lr = 2e-4)

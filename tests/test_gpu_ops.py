@@ -832,6 +832,35 @@ def test_pack_weight_pair(dev, shape):
             assert a[1:] == b[1:] and torch.equal(a[0], b[0])
 
 
+@pytest.mark.parametrize("case", [(3, 16, 64, 64, 16, 3, False), (2, 16, 64, 96, 32, 3, True), (2, 32, 40, 64, 64, 1, True), (3, 32, 32, 32, 32, 3, False),
+                                  (2, 64, 24, 40, 32, 3, False), (2, 128, 16, 16, 128, 3, False), (4, 64, 32, 32, 64, 3, True)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_conv2d_wgrad_with_bias_gradient(dev, case, dtype):
+    """gan_conv2d_wgrad_bias: the weight gradient is the one gan_conv2d_wgrad returns (bf16: bit for bit, same kernels) and the
+    bias gradient equals the fp64 sum of gy over (n, y, x) -- from the thin kernel's extra MFMA (first five cases in
+    bf16), from the channel-sum fallback elsewhere; both accumulate flags; ragged tiles; pooled gy (half resolution)."""
+    import gan_amd.functional as GF
+
+    n, cin, h, w, cout, k, pooled = case
+    pad = (k - 1) // 2
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(n, cin, h, w, generator=g).to(dev).to(dtype).contiguous(memory_format=torch.channels_last)
+    gh, gw_ = (h // 2, w // 2) if pooled else (h, w)
+    gy = torch.randn(n, cout, gh, gw_, generator=g).to(dev).to(dtype).contiguous(memory_format=torch.channels_last)
+    ref_dw = GF.raw_conv2d_wgrad(x, gy, k, k, pad, pad, x_slope=0.2, pooled=pooled)
+    ref_db = gy.double().sum(dim=(0, 2, 3))
+    dw, db = GF.raw_conv2d_wgrad(x, gy, k, k, pad, pad, x_slope=0.2, pooled=pooled, bias=True)
+    if dtype == torch.bfloat16:
+        assert torch.equal(dw, ref_dw)
+    else:  # (the fp32 kernel adds its split-K partials with atomics: the order, and so the last bit, varies)
+        assert rel_err(dw, ref_dw) < 1e-6
+    assert rel_err(db, ref_db) < 1e-5, rel_err(db, ref_db)
+    slot_w = torch.full_like(ref_dw, 0.5)
+    slot_b = torch.full((cout,), -2.0, device=dev)
+    GF.raw_conv2d_wgrad(x, gy, k, k, pad, pad, x_slope=0.2, pooled=pooled, into=slot_w, bias=True, bias_into=slot_b)
+    assert rel_err(slot_w, ref_dw.double() + 0.5) < 1e-6 and rel_err(slot_b, ref_db - 2.0) < 1e-5
+
+
 def test_prepack_weights_multi(dev):
     """gan_pack_weights_multi: every image (and DemodFn's tap sums) of a list of weights from one launch == the single
     packs bit for bit; the caches then serve pack_weight / DemodFn without a launch; a second call with nothing stale does
