@@ -68,10 +68,13 @@ struct ThinWCfg {
     static constexpr int WR = 4 / WT, ROWS = TH / WR, NT = (KS * KS + WT - 1) / WT;
     static constexpr int NCX = ((NPX + 7) / 8) * 8 * (CIN / 8), NCG = NPG * (COUT / 8);
     static constexpr int X_BYTES = CGI * PLX, G_BYTES = CGO * PLG, LDS_BYTES = X_BYTES + G_BYTES;
+    // waves per SIMD the register allocation must leave room for: four workgroups per CU fit in LDS on the smallest
+    // tiles, and the 16 -> 32 3x3 variant sits at 128 registers (the bias sums pushed it to 135: 236 -> 343 us)
+    static constexpr int MIN_WAVES = (LDS_BYTES + 4096) * 4 <= 160 * 1024 && NT * CGO * CGI * 4 <= 72 ? 4 : 2;
 };
 
 template <int CIN, int COUT, int KS, int TH, int WT>
-__global__ void __launch_bounds__(256, 2) conv_thin_wgrad_k(const ThinWArgs p) {
+__global__ void __launch_bounds__(256, (ThinWCfg<CIN, COUT, KS, TH, WT>::MIN_WAVES)) conv_thin_wgrad_k(const ThinWArgs p) {
     typedef ThinWCfg<CIN, COUT, KS, TH, WT> C;
     constexpr int CGI = C::CGI, CGO = C::CGO, HWD = C::HWD, NPX = C::NPX, PLX = C::PLX, PLG = C::PLG;
     constexpr int ROWS = C::ROWS, NT = C::NT, CPX = CIN / 8, CPG = COUT / 8;

@@ -307,11 +307,10 @@ static int wgrad_impl(const void* x, const void* gy, float* dw, int Cout_out, in
     if (dtype == GAN_BF16) {
         int rc = gan_conv2d_wgrad_thin(x, gy, dwo, in_scale, N, H, W, Cin, up2, Ho, Wo, Cout, kh, kw, py, px, workspace,
                                        workspace_floats, nullptr, fu, st);
-        if (rc != 0) return rc < 0 ? rc : GAN_OK;  // (the thin kernel sums gy on the way: dwo.bias)
-        dwo.bias = nullptr;
+        if (rc != 0) return rc < 0 ? rc : GAN_OK;  // (the thin and the tiled kernel sum gy on the way: dwo.bias)
         rc = gan_conv2d_wgrad_tiled(x, gy, dwo, in_scale, N, H, W, Cin, up2, Ho, Wo, Cout, kh, kw, py, px, workspace,
                                     workspace_floats, fu, st);
-        if (rc != 0) return rc < 0 ? rc : bias_by_sum();
+        if (rc != 0) return rc < 0 ? rc : (rc == 2 ? bias_by_sum() : GAN_OK);
     }
     dwo.bias = nullptr;
     // register-staged kernel: fp32 atomics into one zeroed, padded slice of the workspace, then the same reducer

@@ -28,6 +28,8 @@ struct TWArgs {
     int ntiles, S, ci_tiles;
     unsigned x_bytes, gy_bytes;
     WgradFuse fu;
+    int want_bias;  // the workgroups of ci tile 0 also sum gy over the pixels (wave 7): Cout floats behind every slice
+    int64_t Lp;     // slice stride: taps * Cout * Cin (+ Cout)
 };
 
 __device__ __forceinline__ uint4 tmod_chunk(uint4 raw, const float* s) {
@@ -59,13 +61,14 @@ __device__ __forceinline__ bf16x8 tr_frag2(const char* plo, const char* phi) {
 #define GAN_TW_LOADERS 4
 #endif
 constexpr int TW_LOADERS = GAN_TW_LOADERS;  // producer waves (waves 3..6); waves 0-2 are MFMA consumers
-constexpr int TW_THREADS = 192 + 64 * TW_LOADERS;
+constexpr int TW_BIAS_WAVE = 3 + TW_LOADERS;  // one more wave: sum_pixels gy = gy^T x ones on the MFMA (the bias gradient)
+constexpr int TW_THREADS = 192 + 64 * TW_LOADERS + 64;
 
 
 // Tile geometry is a template parameter: the producers turn a chunk index into (image, row, column) with
 // divisions by HALO and HWD for every 16-byte load, which as run-time divisions made them VALU-bound
 // (PMC: consumers waited 67 % of their cycles on the stage barrier).
-template <int KS, int TWL, int THL, int NBL, bool MOD>
+template <int KS, int TWL, int THL, int NBL, bool MOD, bool BIAS>
 __global__ void __launch_bounds__(TW_THREADS) conv_wgrad_tiled_k(const TWArgs p) {
     extern __shared__ __attribute__((aligned(256))) char tw_lds[];
     constexpr int NT = KS;  // taps (dx) per consumer wave
@@ -83,7 +86,42 @@ __global__ void __launch_bounds__(TW_THREADS) conv_wgrad_tiled_k(const TWArgs p)
 
     f32x4 acc[NT][4][4];
 
-    if (wave >= 3) {
+    if (BIAS && wave == TW_BIAS_WAVE) {  // (a template flag: with the branch compiled in, the consumers spill 12-36 bytes more and lose 12 %)
+        // ================= the bias gradient: the gy planes of every stage against a fragment of ones ==============
+        // (the consumers' 192 accumulator registers leave no room for it; a wave of its own has its own registers and
+        // adds 16 MFMAs per tile to a SIMD that runs 192.  Every column of the result holds the sum.)
+        const bool act = p.want_bias && ci0 == 0;
+        f32x4 accb[4];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) accb[o] = f32x4{0.f, 0.f, 0.f, 0.f};
+        bf16x8 ones;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
+        for (int t = t0; t < t1; ++t) {
+            __syncthreads();  // tile t is in its stage (the consumers' barrier)
+            if (!act) continue;
+            const char* const gl = tw_lds + ((t - t0) & 1) * BUF + 4 * PLX;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int Plo = ks * 32 + 4 * g + q, Phi = Plo + 16;
+#pragma unroll
+                for (int o = 0; o < 4; ++o) {
+                    const bf16x8 a = tr_frag2(gl + o * PLG + Plo * 32 + pp * 8, gl + o * PLG + Phi * 32 + pp * 8);
+                    accb[o] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, ones, accb[o], 0, 0, 0);
+                }
+            }
+        }
+        if (act && li == 0) {
+            float* __restrict__ dst = p.ws + (int64_t)s * p.Lp + (int64_t)KS * KS * p.Cout * p.Cin;
+#pragma unroll
+            for (int o = 0; o < 4; ++o)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int co = co0 + o * 16 + g * 4 + r;
+                    if (co < p.Cout) dst[co] = accb[o][r];
+                }
+        }
+    } else if (wave >= 3) {
         // ================= producers: tile t -> LDS stage (t - t0) & 1, TW_U loads in flight per lane ====
         typedef unsigned v4u __attribute__((ext_vector_type(4)));
         constexpr unsigned INV = 0x80000000u;  // past num_records (tensors < 2^31 bytes): the load returns zeros
@@ -239,7 +277,7 @@ __global__ void __launch_bounds__(TW_THREADS) conv_wgrad_tiled_k(const TWArgs p)
         }
         // ---- partial tile -> workspace slice s, final layout [tap][Cout][Cin] (3x3: one tap row per wave)
         if (KS != 1 && wave < KS) {
-            float* __restrict__ slice = p.ws + (int64_t)s * KS * KS * p.Cout * p.Cin;
+            float* __restrict__ slice = p.ws + (int64_t)s * p.Lp;
 #pragma unroll
             for (int dx = 0; dx < NT; ++dx) {
                 float* __restrict__ dst = slice + (int64_t)(wave * KS + dx) * p.Cout * p.Cin;
@@ -268,8 +306,8 @@ __global__ void __launch_bounds__(TW_THREADS) conv_wgrad_tiled_k(const TWArgs p)
                     for (int r = 0; r < 4; ++r) red[wave * 4096 + (o * 16 + g * 4 + r) * 64 + i * 16 + li] = acc[0][o][i][r];
         }
         __syncthreads();
-        float* __restrict__ slice = p.ws + (int64_t)s * p.Cout * p.Cin;
-        for (int e = tid; e < 4096; e += TW_THREADS) {
+        float* __restrict__ slice = p.ws + (int64_t)s * p.Lp;
+        for (int e = tid; e < 4096; e += (int)blockDim.x) {
             const int co = co0 + (e >> 6), ci = ci0 + (e & 63);
             if (co < p.Cout && ci < p.Cin) slice[(int64_t)co * p.Cin + ci] = red[e] + red[4096 + e] + red[8192 + e];
         }
@@ -378,10 +416,10 @@ int64_t gan_wgrad_tiled_workspace(int N, int Ho, int Wo, int Cin, int Cout, int 
     if ((int64_t)N * Ho * Wo * (Cin > Cout ? Cin : Cout) >= (1LL << 30)) return 0;  // 32-bit byte offsets, INV past the end
     const TiledPlan pl = plan_tiled(N, Ho, Wo, Cin, Cout, kh);
     if (!pl.ok) return 0;
-    return (int64_t)pl.S * kh * kw * Cout * Cin;
+    return (int64_t)pl.S * ((int64_t)kh * kw * Cout * Cin + Cout);  // (room for the channel sums whether or not a call wants them)
 }
 
-// 1 = served, 0 = not eligible / workspace too small, < 0 = error.
+// 1 = served, 2 = dw served but not dwo.bias, 0 = not eligible / workspace too small, < 0 = error.
 int gan_conv2d_wgrad_tiled(const void* x, const void* gy, const DwOut& dwo, const float* in_scale, int N, int H, int W,
                            int Cin, int up2, int Ho, int Wo, int Cout, int kh, int kw, int py, int px, float* ws,
                            int64_t ws_floats, const WgradFuse& fu, hipStream_t st) {
@@ -396,13 +434,20 @@ int gan_conv2d_wgrad_tiled(const void* x, const void* gy, const DwOut& dwo, cons
     a.x_bytes = (unsigned)((int64_t)N * H * W * Cin * 2);
     a.gy_bytes = (unsigned)(((int64_t)N * (Ho >> fu.gy_up2) * (Wo >> fu.gy_up2)) * Cout * 2);
     a.tiles_x = pl.tiles_x; a.tiles_y = pl.tiles_y; a.ntiles = pl.ntiles; a.S = pl.S; a.ci_tiles = pl.ci_tiles;
+    // The bias wave costs the kernel ~12 % (compiled in, the consumers spill 12-36 bytes more: 157 against 132 us on
+    // 128 ch @ 32^2, batch 256) and saves a channel-sum pass and its fold (12-17 us): taken where 12 % of the kernel is
+    // less than that, i.e. below ~65 us of MFMA work.
+    a.want_bias = dwo.bias != nullptr && in_scale == nullptr && (int64_t)N * Ho * Wo * Cin * Cout <= (1LL << 31);
+    a.Lp = (int64_t)kh * kw * Cout * Cin + (a.want_bias ? Cout : 0);
+    const dim3 block(a.want_bias ? TW_THREADS : TW_THREADS - 64);  // (without the bias wave the barriers count seven waves)
     const dim3 grid((unsigned)(pl.co_tiles * pl.ci_tiles), (unsigned)pl.S);
-#define TW_LAUNCH(KS_, TWL_, THL_, NBL_)                                                                                \
-    do {                                                                                                             \
-        if (in_scale)                                                                                                \
-            hipLaunchKernelGGL((conv_wgrad_tiled_k<KS_, TWL_, THL_, NBL_, true>), grid, dim3(TW_THREADS), (size_t)pl.lds, st, a);  \
-        else                                                                                                         \
-            hipLaunchKernelGGL((conv_wgrad_tiled_k<KS_, TWL_, THL_, NBL_, false>), grid, dim3(TW_THREADS), (size_t)pl.lds, st, a); \
+#define TW_LAUNCH2(KS_, TWL_, THL_, NBL_, MOD_, BIAS_) \
+    hipLaunchKernelGGL((conv_wgrad_tiled_k<KS_, TWL_, THL_, NBL_, MOD_, BIAS_>), grid, block, (size_t)pl.lds, st, a)
+#define TW_LAUNCH(KS_, TWL_, THL_, NBL_)                                  \
+    do {                                                                  \
+        if (in_scale) TW_LAUNCH2(KS_, TWL_, THL_, NBL_, true, false);     \
+        else if (a.want_bias) TW_LAUNCH2(KS_, TWL_, THL_, NBL_, false, true); \
+        else TW_LAUNCH2(KS_, TWL_, THL_, NBL_, false, false);             \
     } while (0)
     if (kh == 3) {
         if (pl.tw_log2 == 5) TW_LAUNCH(3, 5, 2, 0);
@@ -421,13 +466,16 @@ int gan_conv2d_wgrad_tiled(const void* x, const void* gy, const DwOut& dwo, cons
         else TW_LAUNCH(1, 2, 2, 3);
     }
 #undef TW_LAUNCH
+#undef TW_LAUNCH2
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         gan_set_error("conv2d_wgrad(tiled): launch failed: %s", hipGetErrorString(e));
         return GAN_ERR_LAUNCH;
     }
-    const int rc = gan_finalize_dw(ws, pl.S, kh * kw, Cout, Cin, dwo, fu.gain, st);
-    return rc == GAN_OK ? 1 : rc;
+    // (gy at half resolution is staged four times per source pixel: the sums come out 4x)
+    const int rc = gan_finalize_dw(ws, pl.S, kh * kw, Cout, Cin, dwo, fu.gain, st, a.want_bias, fu.gy_up2 ? 0.25f : 1.f);
+    if (rc != GAN_OK) return rc;
+    return dwo.bias != nullptr && !a.want_bias ? 2 : 1;  // 2: dw served, the bias gradient is left to the caller
 }
 
 int gan_finalize_dw(const float* ws, int S, int taps, int Cout, int Cin, const DwOut& dwo, float gain, hipStream_t st, int bias_plane,
