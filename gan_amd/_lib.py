@@ -58,7 +58,7 @@ _SIGNATURES = {
     "gan_demod_bwd": (c_int, [c_void_p] * 7 + [c_int] * 5 + [c_void_p]),
     "gan_pack_weight": (c_int, [c_void_p, c_int, c_void_p, c_int] + [c_int] * 7 + [c_void_p]),
     "gan_pad_channels": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int64, c_int64, c_void_p, c_int] + [c_int] * 5 + [c_void_p]),
-    "gan_pack_weights_multi": (c_int, [c_void_p, c_int, c_int64, c_int, c_int, c_void_p]),
+    "gan_pack_weights_multi": (c_int, [c_void_p, c_int, c_int64, c_int, c_int, c_int, c_void_p]),
     "gan_pack_weight_pair": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int] + [c_int] * 5 + [c_void_p]),
     "gan_up2_add": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "gan_mbstd_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_int, c_void_p]),

@@ -1253,37 +1253,16 @@ extern "C" int gan_pack_weight_pair(const void* w, int w_dtype, void* out, int c
 // for ~25 us of traffic).  table: `count` rows of 12 int64 in device memory:
 //   [0] w  [1] out (forward image or 0)  [2] out_t (transposed image or 0)  [3] wsq (fp32 [Cout][Cin] tap sums of W^2, or 0)
 //   [4] first workgroup of this row  [5] Cout  [6] Cin  [7] taps  [8] cols_p  [9] Kpad  [10] cols_p_t  [11] Kpad_t
-// A row owns ceil((Cout*Kpad/8 + Cin*Kpad_t/8 + Cout*Cin) / 256) workgroups (absent pieces count 0; both padded row
-// lengths are multiples of 32 and both padded channel counts multiples of 8; images 16-byte aligned, < 2^31 elements).
-// eight consecutive k of one image row (one 16-byte store in bf16): cols_p % 8 == 0, so they share a tap
-template <typename TI, typename TO>
-__device__ __forceinline__ void pack_weight_oct(const TI* __restrict__ w, TO* __restrict__ out, int e, int Cin, int taps, int cols, int cols_p,
-                                                int Kpad, int transposed) {
-    const int k8 = Kpad >> 3;
-    const int r = e / k8, k = (e - r * k8) * 8;
-    const int tap = k / cols_p, c = k - tap * cols_p;
-    TO v[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        float f = 0.f;
-        if (tap < taps && c + j < cols) {
-            const int co = transposed ? c + j : r, ci = transposed ? r : c + j;
-            const int t = transposed ? taps - 1 - tap : tap;
-            f = (float)w[((int64_t)co * Cin + ci) * taps + t];
-        }
-        v[j] = (TO)f;
-    }
-    TO* __restrict__ dst = out + (int64_t)r * Kpad + k;
-    if (sizeof(TO) == 2) {
-        *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(v);
-    } else {
-        *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(v);
-        *reinterpret_cast<uint4*>(dst + 4) = *reinterpret_cast<const uint4*>(v + 4);
-    }
-}
-
+// A workgroup owns a 64 (co) x 64 (ci) tile of one weight with all its taps: the tile is read ONCE, coalesced (a
+// (co, ci) pair is `taps` consecutive elements), the tap sums are taken from the fp32 values, the tile is parked in LDS
+// in the output type, and both images are written from there in 16-byte pieces that form 128-byte runs (64 ci of one
+// (co, tap) / 64 co of one (ci, tap)).  A row owns ceil(max(Cout, cols_p_t) / 64) * ceil(max(Cin, cols_p) / 64)
+// workgroups; dynamic LDS = 4096 * max taps * sizeof(TO).  (First version: a thread per output element gathered its
+// source through the strides of the permutation -- 80 us per launch; the transposed image read a new sector per element.)
 template <typename TI, typename TO>
 __global__ void __launch_bounds__(256) pack_weights_multi_k(const long long* __restrict__ table, int count) {
+    extern __shared__ __attribute__((aligned(16))) char pw_lds[];
+    TO* const tile = reinterpret_cast<TO*>(pw_lds);
     __shared__ int which;
     for (int i = threadIdx.x; i < count; i += 256) {
         const long long b0 = table[i * 12 + 4];
@@ -1297,32 +1276,93 @@ __global__ void __launch_bounds__(256) pack_weights_multi_k(const long long* __r
     TO* __restrict__ out_t = reinterpret_cast<TO*>(d[2]);
     float* __restrict__ wsq = reinterpret_cast<float*>(d[3]);
     const int Cout = (int)d[5], Cin = (int)d[6], taps = (int)d[7];
-    // work items of the row: 8-element pieces of the two images, then one (co, ci) tap sum each
-    const int n0 = out ? Cout * ((int)d[9] >> 3) : 0, n1 = out_t ? Cin * ((int)d[11] >> 3) : 0, n2 = wsq ? Cout * Cin : 0;
-    const int e = (int)((long long)blockIdx.x - d[4]) * 256 + threadIdx.x;
-    if (e < n0) {
-        pack_weight_oct<TI, TO>(w, out, e, Cin, taps, Cin, (int)d[8], (int)d[9], 0);
-    } else if (e < n0 + n1) {
-        pack_weight_oct<TI, TO>(w, out_t, e - n0, Cin, taps, Cout, (int)d[10], (int)d[11], 1);
-    } else if (e < n0 + n1 + n2) {
-        const int64_t q = e - n0 - n1;
-        float a = 0.f;
-        for (int t = 0; t < taps; ++t) {
-            const float v = (float)w[q * taps + t];
-            a = fmaf(v, v, a);
+    const int cols_p = (int)d[8], Kpad = (int)d[9], cols_p_t = (int)d[10], Kpad_t = (int)d[11];
+    const int ci_span = cols_p > Cin ? cols_p : Cin, ci_tiles = (ci_span + 63) >> 6;
+    const int local = (int)((long long)blockIdx.x - d[4]);
+    const int co0 = (local / ci_tiles) * 64, ci0 = (local % ci_tiles) * 64;
+    const int tid = threadIdx.x;
+    // ---- stage: pair p = (co, ci) -> `taps` consecutive source elements; zeros outside the weight
+    for (int p = tid; p < 4096; p += 256) {
+        const int co = co0 + (p >> 6), ci = ci0 + (p & 63);
+        TO* __restrict__ dst = tile + p * taps;
+        if (co < Cout && ci < Cin) {
+            const TI* __restrict__ src = w + ((int64_t)co * Cin + ci) * taps;
+            float a = 0.f;
+            for (int t = 0; t < taps; ++t) {
+                const float v = (float)src[t];
+                a = fmaf(v, v, a);
+                dst[t] = (TO)v;
+            }
+            if (wsq) wsq[(int64_t)co * Cin + ci] = a;
+        } else {
+            for (int t = 0; t < taps; ++t) dst[t] = (TO)0.f;
         }
-        wsq[q] = a;
+    }
+    __syncthreads();
+    constexpr int PW = 16 / (int)sizeof(TO);  // elements per 16-byte piece (8 bf16 / 4 fp32)
+    constexpr int PPR = 64 / PW;              // pieces per 64-channel run
+    const int npieces = 64 * taps * PPR;
+    // ---- forward image: out[co][tap * cols_p + ci], rows co < Cout, columns < cols_p
+    if (out) {
+        for (int e = tid; e < npieces; e += 256) {
+            const int pc = e % PPR, rest = e / PPR, tap = rest % taps, r = rest / taps;
+            const int co = co0 + r, c = ci0 + pc * PW;
+            if (co >= Cout || c >= cols_p) continue;
+            TO v[PW];
+#pragma unroll
+            for (int j = 0; j < PW; ++j) v[j] = tile[(r * 64 + pc * PW + j) * taps + tap];
+            TO* __restrict__ dst = out + (int64_t)co * Kpad + tap * cols_p + c;
+            *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(v);
+        }
+        if (ci0 == 0) {  // the zero tail of each row: k in [taps * cols_p, Kpad)
+            const int tail = (Kpad - taps * cols_p) / PW;
+            for (int e = tid; e < 64 * tail; e += 256) {
+                const int co = co0 + e / tail;
+                if (co < Cout) *reinterpret_cast<uint4*>(out + (int64_t)co * Kpad + taps * cols_p + (e % tail) * PW) = make_uint4(0, 0, 0, 0);
+            }
+        }
+    }
+    // ---- transposed image: out_t[ci][(taps - 1 - tap) * cols_p_t + co], rows ci < Cin, columns < cols_p_t
+    if (out_t) {
+        for (int e = tid; e < npieces; e += 256) {
+            const int pc = e % PPR, rest = e / PPR, tap = rest % taps, r = rest / taps;
+            const int ci = ci0 + r, c = co0 + pc * PW;
+            if (ci >= Cin || c >= cols_p_t) continue;
+            TO v[PW];
+#pragma unroll
+            for (int j = 0; j < PW; ++j) v[j] = tile[((pc * PW + j) * 64 + r) * taps + tap];
+            TO* __restrict__ dst = out_t + (int64_t)ci * Kpad_t + (taps - 1 - tap) * cols_p_t + c;
+            *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(v);
+        }
+        if (co0 == 0) {
+            const int tail = (Kpad_t - taps * cols_p_t) / PW;
+            for (int e = tid; e < 64 * tail; e += 256) {
+                const int ci = ci0 + e / tail;
+                if (ci < Cin) *reinterpret_cast<uint4*>(out_t + (int64_t)ci * Kpad_t + taps * cols_p_t + (e % tail) * PW) = make_uint4(0, 0, 0, 0);
+            }
+        }
     }
 }
 
-extern "C" int gan_pack_weights_multi(const int64_t* table, int count, int64_t blocks, int w_dtype, int out_dtype, gan_stream_t stream) {
+extern "C" int gan_pack_weights_multi(const int64_t* table, int count, int64_t blocks, int max_taps, int w_dtype, int out_dtype,
+                                      gan_stream_t stream) {
     GAN_CHECK_ARG(count >= 0 && blocks >= 0 && blocks < (1LL << 31), "pack_weights_multi: bad sizes");
     GAN_CHECK_ARG((w_dtype == GAN_F32 || w_dtype == GAN_BF16) && (out_dtype == GAN_F32 || out_dtype == GAN_BF16), "pack_weights_multi: bad dtype");
     if (count == 0 || blocks == 0) return GAN_OK;
     GAN_CHECK_ARG(table, "pack_weights_multi: null table");
+    const size_t lds = (size_t)4096 * (size_t)(max_taps > 0 ? max_taps : 0) * (out_dtype == GAN_BF16 ? 2 : 4);
+    GAN_CHECK_ARG(max_taps >= 1 && lds <= 150 * 1024, "pack_weights_multi: a 64 x 64 tile with %d taps does not fit LDS (pack that weight alone)", max_taps);
     hipStream_t st = (hipStream_t)stream;
-#define PACKM_LAUNCH(TI, TO) \
-    hipLaunchKernelGGL((pack_weights_multi_k<TI, TO>), dim3((unsigned)blocks), dim3(256), 0, st, (const long long*)table, count)
+    // more than 64 KB of dynamic LDS needs the attribute (set on every call: it is per device, and cheap)
+#define PACKM_LAUNCH(TI, TO)                                                                                                          \
+    do {                                                                                                                              \
+        if (lds > 64 * 1024 &&                                                                                                        \
+            hipFuncSetAttribute((const void*)pack_weights_multi_k<TI, TO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { \
+            gan_set_error("pack_weights_multi: cannot reserve %zu bytes of LDS", lds);                                                \
+            return GAN_ERR_LAUNCH;                                                                                                    \
+        }                                                                                                                             \
+        hipLaunchKernelGGL((pack_weights_multi_k<TI, TO>), dim3((unsigned)blocks), dim3(256), lds, st, (const long long*)table, count); \
+    } while (0)
     if (w_dtype == GAN_F32 && out_dtype == GAN_BF16) PACKM_LAUNCH(float, bf16);
     else if (w_dtype == GAN_F32) PACKM_LAUNCH(float, float);
     else if (out_dtype == GAN_BF16) PACKM_LAUNCH(bf16, bf16);

@@ -566,11 +566,13 @@ def prepack_weights(weights) -> bool:
             tr = sorted(m for m, t in seen[1] if t)
             if len(fwd) > 1 or len(tr) > 1 or (not fwd and not tr):
                 continue  # several paddings of one orientation: left to pack_weight
+            if 4096 * w.shape[2] * w.shape[3] * (2 if dt == torch.bfloat16 else 4) > 150 * 1024:
+                continue  # a 64 x 64 tile with all its taps must fit LDS (gan_pack_weights_multi)
             plan.append((w, dt, fwd[0] if fwd else None, tr[0] if tr else None, want_wsq))
             want_wsq = False
             for m, t in seen[1]:
                 stale |= not _cache_valid((id(w), dt, m, t), w)
-        if want_wsq:
+        if want_wsq and 4096 * w.shape[2] * w.shape[3] * 4 <= 150 * 1024:
             plan.append((w, torch.float32, None, None, True))
     if not plan or not stale:
         return False
@@ -590,26 +592,23 @@ def prepack_weights(weights) -> bool:
             taps = kh * kw
             img_f = img_t = wsq = None
             row = [w.data_ptr(), 0, 0, 0, 0, cout, cin, taps, 0, 0, 0, 0]
-            n = 0
             if mf is not None:
                 cp = cin + ((-cin) % mf)
                 kpad = taps * cp + ((-taps * cp) % 32)
                 img_f = (_packed_rows(cout, kpad, dt, dev), cp, kpad)
                 row[1], row[8], row[9] = img_f[0].data_ptr(), cp, kpad
-                n += cout * kpad // 8
             if mt is not None:
                 cp = cout + ((-cout) % mt)
                 kpad = taps * cp + ((-taps * cp) % 32)
                 img_t = (_packed_rows(cin, kpad, dt, dev), cp, kpad)
                 row[2], row[10], row[11] = img_t[0].data_ptr(), cp, kpad
-                n += cin * kpad // 8
             if q:
                 wsq = torch.empty((cout, cin), dtype=torch.float32, device=dev)
                 row[3] = wsq.data_ptr()
-                n += cout * cin
-            tab = launches.setdefault((w.dtype, dt), {"rows": [], "blocks": 0})
+            tab = launches.setdefault((w.dtype, dt), {"rows": [], "blocks": 0, "taps": 0})
             row[4] = tab["blocks"]
-            tab["blocks"] += -(-n // 256)
+            tab["blocks"] += -(-max(cout, row[10]) // 64) * -(-max(cin, row[8]) // 64)  # 64 x 64 (co x ci) tiles
+            tab["taps"] = max(tab["taps"], taps)
             tab["rows"].append(row)
             entries.append((w, dt, mf, mt, img_f, img_t, wsq))
         for tab in launches.values():
@@ -617,7 +616,7 @@ def prepack_weights(weights) -> bool:
         group = _PREPACK_GROUPS[gkey] = {"sig": sig, "launches": launches, "entries": entries, "keep": [weakref.ref(w) for w in weights]}
     lib = _lib.load()
     for (wdt, odt), tab in group["launches"].items():
-        check(lib.gan_pack_weights_multi(ptr(tab["table"]), len(tab["rows"]), tab["blocks"], _DT_CODE[wdt], _DT_CODE[odt],
+        check(lib.gan_pack_weights_multi(ptr(tab["table"]), len(tab["rows"]), tab["blocks"], tab["taps"], _DT_CODE[wdt], _DT_CODE[odt],
                                          stream_of(tab["table"])), "gan_pack_weights_multi")
     for w, dt, mf, mt, img_f, img_t, wsq in group["entries"]:
         ref, ver = weakref.ref(w), (w._version, w.data_ptr())

@@ -226,10 +226,11 @@ int gan_pack_weight_pair(const void* w, int w_dtype, void* out, int cols_p, int 
  * re-packed once per optimizer step, and ~60 launches of 5-8 us per iteration become two).  `table`: device memory,
  * `count` rows of 12 int64: [0] w, [1] out or 0, [2] out_t or 0, [3] wsq (fp32 [Cout][Cin] sums over the taps of W^2,
  * the first factor of gan_demod_fwd) or 0, [4] first workgroup of the row, [5] Cout, [6] Cin, [7] kh*kw, [8] cols_p,
- * [9] Kpad, [10] cols_p_t, [11] Kpad_t; a row owns ceil((Cout*Kpad/8 + Cin*Kpad_t/8 + Cout*Cin) / 256) workgroups
- * (absent pieces count 0; a thread writes 8 consecutive k: cols_p % 8 == 0, Kpad % 32 == 0, images 16-byte aligned) and
- * `blocks` is their total.  All rows share w_dtype and out_dtype. */
-int gan_pack_weights_multi(const int64_t* table, int count, int64_t blocks, int w_dtype, int out_dtype, gan_stream_t stream);
+ * [9] Kpad, [10] cols_p_t, [11] Kpad_t (cols_p % 8 == 0, Kpad % 32 == 0, images 16-byte aligned; the padding of an
+ * absent image 0).  A workgroup owns a 64 x 64 (co x ci) tile of one weight with all its taps, staged in LDS: a row owns
+ * ceil(max(Cout, cols_p_t) / 64) * ceil(max(Cin, cols_p) / 64) workgroups and `blocks` is their total; max_taps = the
+ * largest kh*kw of the table, 4096 * max_taps * sizeof(out element) <= 150 KB.  All rows share w_dtype and out_dtype. */
+int gan_pack_weights_multi(const int64_t* table, int count, int64_t blocks, int max_taps, int w_dtype, int out_dtype, gan_stream_t stream);
 
 /* Image-like tensors (C < 8: the RGB inputs / outputs of the from-RGB and to-RGB convolutions,
  * progressive_gan.py:61, stylegan2.py:124) -> channels-last, zero padded to Cp channels (multiple of 8), in

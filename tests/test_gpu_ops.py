@@ -869,7 +869,7 @@ def test_prepack_weights_multi(dev):
     import gan_amd.functional as GF
 
     g = torch.Generator().manual_seed(12)
-    shapes = [(32, 16, 3, 3), (16, 3, 1, 1), (513, 24, 3, 3), (24, 40, 3, 3), (8, 8, 1, 1)]
+    shapes = [(32, 16, 3, 3), (16, 3, 1, 1), (513, 24, 3, 3), (24, 40, 3, 3), (8, 8, 1, 1), (72, 130, 4, 4), (136, 200, 3, 3)]
     ws = [torch.nn.Parameter(torch.randn(*sh, generator=g).to(dev)) for sh in shapes]
     GF.drop_packed()
     GF._PACK_SEEN.clear()
@@ -884,6 +884,7 @@ def test_prepack_weights_multi(dev):
             want[(i, False)] = (mf, GF.pack_weight(w, torch.bfloat16, mf, False))
         if i != 3:
             want[(i, True)] = (mt, GF.pack_weight(w, torch.bfloat16, mt, True))
+    want32 = {tr: GF.pack_weight(ws[6], torch.float32, 8, tr) for tr in (False, True)}  # fp32 images: a 147 KB tile in LDS
     s = (torch.randn(5, 40, generator=g) * 0.5 + 1).to(dev)
     d0 = GF.DemodFn.apply(s, ws[3])  # records ws[3] as a demodulated weight
     GF.drop_packed()
@@ -894,6 +895,9 @@ def test_prepack_weights_multi(dev):
         got = GF.pack_weight(ws[i], torch.bfloat16, m, tr)
         assert got[1:] == ref[1:] and torch.equal(got[0], ref[0]), (i, tr)
         bufs[(i, tr)] = got[0].data_ptr()
+    for tr, ref in want32.items():
+        got = GF.pack_weight(ws[6], torch.float32, 8, tr)
+        assert got[1:] == ref[1:] and torch.equal(got[0], ref[0]), ("fp32", tr)
     assert GF.PACK_STATS[1] == miss0  # all served from the group's buffers
     hit = GF._WSQ_CACHE[id(ws[3])]
     assert torch.equal(hit[2], ws[3].detach().square().sum(dim=(2, 3)))  or rel_err(hit[2], ws[3].detach().double().square().sum(dim=(2, 3))) < 1e-6
