@@ -219,6 +219,28 @@ def side_recipe(device, recipe, img_size, base_dim, batch, steps=10, warmup=2):
                           f"StyleGAN2 hinge+R1, {img_size}x{img_size}, base_dim {base_dim}, batch {batch}, Adam(2e-4, (0, 0.9)), bf16"))
 
 
+def share_leg(device, args, batch, steps=10, warmup=2):
+    """The per-GPU share of the fixed global batch at N = 256 / batch ranks, on this one GPU (graph replay, no all-reduce):
+    what the strong-scaling curve can reach before any communication."""
+    from gan_amd.train_celeba import synthetic_reals
+
+    ns = argparse.Namespace(global_batch=batch, micro_batch=256, recipe="stylegan2", img_size=args.img_size, base_dim=args.base_dim, fp32=args.fp32,
+                            no_graph=args.no_graph)
+    cfg, trainer, micro = make_trainer(ns, device, 1)
+    next_reals = synthetic_reals(cfg, device, micro, seed=0)
+    for _ in range(cfg.graph_warmup + 1 + warmup):
+        trainer.train_step(next_reals)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        trainer.train_step(next_reals)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    del trainer
+    torch.cuda.empty_cache()
+    return round(dt * 1e3, 2)
+
+
 def micro_leg(device):
     """BASELINE config[1]: benchmark_upfirdn2d.py shapes, bf16 channels_last, 3x3 FIR, up = down = 1, pad 1;
     plus 2x up / 2x down with the 4-tap binomial FIR and the fused bias + leaky-ReLU.  Algorithmic bytes =
@@ -424,6 +446,9 @@ def main():
         if not args.no_side and args.recipe == "stylegan2" and args.img_size == 256:
             side = {"config3_stylegan2_64": side_recipe(device, "stylegan2", 64, 64, 64),
                     "config5_dcgan_wgan_gp": side_recipe(device, "dcgan", 64, 16, 64)}
+            if args.global_batch == 256:
+                # ms per iteration of the per-GPU share at 2 / 4 / 8 ranks, run on this one GPU without the all-reduce
+                side["per_gpu_share_ms"] = {str(b): share_leg(device, args, b) for b in (128, 64, 32)}
         if not args.no_micro:
             micro_res = micro_leg(device)
         if roof is not None and not args.no_pmc:
@@ -467,6 +492,7 @@ def main():
             "kernels": fams,
             "cpu_baseline": cpu,
             "upfirdn2d": micro_res,
+            "per_gpu_share_ms": side.pop("per_gpu_share_ms", None) if side else None,
             "other_configs": side,
         }
         _emit(line)
