@@ -294,6 +294,11 @@ __global__ void __launch_bounds__(WAVES * 64, 2) conv_wide_halo_k(const HaloArgs
         unsigned obase;  // byte offset of the pixel's channel 0 in y / aux / resid, HALO_INV when this lane has none
         float nz;
     };
+    // The output stages are compiled three times -- plain (scale, bias, activation), with the input-gradient stages
+    // (mask / residual), with everything -- and picked once per workgroup: tested per fragment, the wave-uniform
+    // branches split the stage code into ~100 basic blocks with a wait in front of most.
+    auto epilogue = [&](auto modc, auto arc) {
+    constexpr bool MOD = decltype(modc)::value, AR = decltype(arc)::value;
     // this lane's output pixel of fragment f (pooling: of the 2x2 window that fragments f, f+1 and lanes frow, frow^1 hold)
     auto out_pixel = [&](const int f) {
         int img, ly, lx;
@@ -305,28 +310,44 @@ __global__ void __launch_bounds__(WAVES * 64, 2) conv_wide_halo_k(const HaloArgs
         const int opix = p.pool ? (q.n * Hy + (oy >> 1)) * Wy + (ox >> 1) : (q.n * Hy + oy) * Wy + ox;
         q.obase = live ? (unsigned)opix * (unsigned)(p.Cout * 2) : HALO_INV;
         q.nz = 0.f;
-        if (p.noise) q.nz = (float)__builtin_bit_cast(bf16, __builtin_amdgcn_raw_buffer_load_b16(rnz, live ? (unsigned)opix * 2u : HALO_INV, 0, 0));
+        if (MOD && p.noise) q.nz = (float)__builtin_bit_cast(bf16, __builtin_amdgcn_raw_buffer_load_b16(rnz, live ? (unsigned)opix * 2u : HALO_INV, 0, 0));
         return q;
     };
     // every output stage on the lane's 4 channels of fragment column i
     auto finish = [&](const int i, const OutPixel& q, const f32x4 a) {
         const unsigned off = (q.obase != HALO_INV && co0[i] < p.Cout) ? q.obase + co0[i] * 2 : HALO_INV;
         float4 d4 = make_float4(1.f, 1.f, 1.f, 1.f);
-        if (p.out_scale)
+        if (MOD && p.out_scale)
             d4 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rosc, off != HALO_INV ? (unsigned)(q.n * p.Cout + co0[i]) * 4u : HALO_INV, 0, 0));
+        // (absent stages are wave-uniform branches: the plain layer is one fma per element, not a mul and two fmas)
         float v[4];
-        v[0] = fmaf(q.nz, nsc[i].x, fmaf(a[0] * gain, d4.x, bia[i].x));
-        v[1] = fmaf(q.nz, nsc[i].y, fmaf(a[1] * gain, d4.y, bia[i].y));
-        v[2] = fmaf(q.nz, nsc[i].z, fmaf(a[2] * gain, d4.z, bia[i].z));
-        v[3] = fmaf(q.nz, nsc[i].w, fmaf(a[3] * gain, d4.w, bia[i].w));
+        if (MOD && p.out_scale) {
+            v[0] = fmaf(a[0] * gain, d4.x, bia[i].x);
+            v[1] = fmaf(a[1] * gain, d4.y, bia[i].y);
+            v[2] = fmaf(a[2] * gain, d4.z, bia[i].z);
+            v[3] = fmaf(a[3] * gain, d4.w, bia[i].w);
+        } else {
+            v[0] = fmaf(a[0], gain, bia[i].x);
+            v[1] = fmaf(a[1], gain, bia[i].y);
+            v[2] = fmaf(a[2], gain, bia[i].z);
+            v[3] = fmaf(a[3], gain, bia[i].w);
+        }
+        if (MOD && p.noise) {
+            v[0] = fmaf(q.nz, nsc[i].x, v[0]);
+            v[1] = fmaf(q.nz, nsc[i].y, v[1]);
+            v[2] = fmaf(q.nz, nsc[i].z, v[2]);
+            v[3] = fmaf(q.nz, nsc[i].w, v[3]);
+        }
+        if (p.slope != 1.f) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = lrelu_f(v[r], p.slope);
-        if (p.aux) {
+            for (int r = 0; r < 4; ++r) v[r] = lrelu_f(v[r], p.slope);
+        }
+        if (AR && p.aux) {
             const bf16x4 a4 = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(raux, off, 0, 0));
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] *= lrelu_mask((float)a4[r], p.aux_slope);
         }
-        if (p.resid) {
+        if (AR && p.resid) {
             const bf16x4 r4 = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(rres, off, 0, 0));
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] += (float)r4[r];
@@ -376,6 +397,10 @@ __global__ void __launch_bounds__(WAVES * 64, 2) conv_wide_halo_k(const HaloArgs
             }
         }
     }
+    };
+    if (p.out_scale || p.noise) epilogue(std::true_type{}, std::true_type{});
+    else if (p.aux || p.resid) epilogue(std::false_type{}, std::true_type{});
+    else epilogue(std::false_type{}, std::false_type{});
 #ifdef GAN_HALO_STAMPS
     STAMP(10);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
