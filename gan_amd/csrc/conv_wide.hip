@@ -21,6 +21,7 @@
 // apply them in a pass of their own for these layers (the tensors are small: <= 134 MB at batch 256), or the
 // register-staged kernel in conv_fwd.hip takes the call.
 #include "common.h"
+#include <type_traits>
 #include <stdlib.h>
 
 namespace {
@@ -247,6 +248,10 @@ __global__ void __launch_bounds__(256, NST == 2 ? 2 : 1) conv_wide_k(const WideA
         bia[i] = (p.bias && cok) ? *reinterpret_cast<const float4*>(p.bias + co0[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
         nsc[i] = (p.noise_scale && cok) ? *reinterpret_cast<const float4*>(p.noise_scale + co0[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    // the output stages in three compiled variants, picked once per workgroup (as conv_wide_halo_k's): the plain layer
+    // issues no loads for the tensors it does not have and one fma per element
+    auto epilogue = [&](auto modc, auto arc) {
+    constexpr bool MOD = decltype(modc)::value, AR = decltype(arc)::value;
 #pragma unroll
     for (int f = 0; f < FP; ++f) {
         const int m = bm0 + wm * 64 + f * 16 + frow;
@@ -256,15 +261,19 @@ __global__ void __launch_bounds__(256, NST == 2 ? 2 : 1) conv_wide_k(const WideA
         const unsigned obase = live ? (unsigned)opix * (unsigned)(p.Cout * 2) : WIDE_INV;
         // every per-pixel load of this fragment row first, then its stores
         float nz = 0.f;
-        if (p.noise) nz = (float)__builtin_bit_cast(bf16, __builtin_amdgcn_raw_buffer_load_b16(rnz, live ? (unsigned)opix * 2u : WIDE_INV, 0, 0));
+        if (MOD && p.noise) nz = (float)__builtin_bit_cast(bf16, __builtin_amdgcn_raw_buffer_load_b16(rnz, live ? (unsigned)opix * 2u : WIDE_INV, 0, 0));
         v2u ax[FC], rs[FC];
         v4u os[FC];
 #pragma unroll
         for (int i = 0; i < FC; ++i) {
             const bool cok = live && co0[i] < p.Cout;
-            ax[i] = __builtin_amdgcn_raw_buffer_load_b64(raux, cok ? obase + co0[i] * 2 : WIDE_INV, 0, 0);
-            rs[i] = __builtin_amdgcn_raw_buffer_load_b64(rres, cok ? obase + co0[i] * 2 : WIDE_INV, 0, 0);
-            os[i] = __builtin_amdgcn_raw_buffer_load_b128(rosc, cok ? (unsigned)(n * p.Cout + co0[i]) * 4u : WIDE_INV, 0, 0);
+            ax[i] = rs[i] = v2u{0u, 0u};
+            os[i] = v4u{0u, 0u, 0u, 0u};
+            if (AR) {  // (absent tensors read zeros past their zero-sized resource)
+                ax[i] = __builtin_amdgcn_raw_buffer_load_b64(raux, cok ? obase + co0[i] * 2 : WIDE_INV, 0, 0);
+                rs[i] = __builtin_amdgcn_raw_buffer_load_b64(rres, cok ? obase + co0[i] * 2 : WIDE_INV, 0, 0);
+            }
+            if (MOD) os[i] = __builtin_amdgcn_raw_buffer_load_b128(rosc, cok ? (unsigned)(n * p.Cout + co0[i]) * 4u : WIDE_INV, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < FC; ++i) {
@@ -276,25 +285,38 @@ __global__ void __launch_bounds__(256, NST == 2 ? 2 : 1) conv_wide_k(const WideA
                     a += quad_xor1(a);
                     a += quad_xor2(a);
                 }
-                v[r] = a * gain;
+                v[r] = a;
             }
-            const float4 d4 = p.out_scale ? __builtin_bit_cast(float4, os[i]) : make_float4(1.f, 1.f, 1.f, 1.f);
-            v[0] = fmaf(nz, nsc[i].x, fmaf(v[0], d4.x, bia[i].x));
-            v[1] = fmaf(nz, nsc[i].y, fmaf(v[1], d4.y, bia[i].y));
-            v[2] = fmaf(nz, nsc[i].z, fmaf(v[2], d4.z, bia[i].z));
-            v[3] = fmaf(nz, nsc[i].w, fmaf(v[3], d4.w, bia[i].w));
+            if (MOD) {
+                const float4 d4 = p.out_scale ? __builtin_bit_cast(float4, os[i]) : make_float4(1.f, 1.f, 1.f, 1.f);
+                v[0] = fmaf(nz, nsc[i].x, fmaf(v[0] * gain, d4.x, bia[i].x));
+                v[1] = fmaf(nz, nsc[i].y, fmaf(v[1] * gain, d4.y, bia[i].y));
+                v[2] = fmaf(nz, nsc[i].z, fmaf(v[2] * gain, d4.z, bia[i].z));
+                v[3] = fmaf(nz, nsc[i].w, fmaf(v[3] * gain, d4.w, bia[i].w));
+            } else {
+                v[0] = fmaf(v[0], gain, bia[i].x);
+                v[1] = fmaf(v[1], gain, bia[i].y);
+                v[2] = fmaf(v[2], gain, bia[i].z);
+                v[3] = fmaf(v[3], gain, bia[i].w);
+            }
             bf16x4 o;
             const bf16x4 a4 = __builtin_bit_cast(bf16x4, ax[i]), r4 = __builtin_bit_cast(bf16x4, rs[i]);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float u = lrelu_f(v[r], p.slope);
-                if (p.aux) u *= lrelu_mask((float)a4[r], p.aux_slope);
-                u += (float)r4[r];  // zeros without a residual (out-of-range load)
+                if (AR) {
+                    if (p.aux) u *= lrelu_mask((float)a4[r], p.aux_slope);
+                    u += (float)r4[r];  // zeros without a residual (out-of-range load)
+                }
                 o[r] = (bf16)u;
             }
             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, o), ry, (live && co0[i] < p.Cout) ? obase + co0[i] * 2 : WIDE_INV, 0, 0);
         }
     }
+    };
+    if (p.out_scale || p.noise) epilogue(std::true_type{}, std::true_type{});
+    else if (p.aux || p.resid) epilogue(std::false_type{}, std::true_type{});
+    else epilogue(std::false_type{}, std::false_type{});
 }
 
 // Split-K fold: y[opix][co..co+3] = stages( sum_z ws[z][m][co..co+3] ), the output stages of conv_wide_k's epilogue on the
