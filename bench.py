@@ -80,7 +80,7 @@ def make_trainer(args, device, world):
             model="stylegan2", img_size=args.img_size, gen_kwargs={"base_dim": args.base_dim}, disc_kwargs={"base_dim": args.base_dim},
             method="hinge", regularizer="r1", batch_size=args.global_batch, optimizer="Adam", optimizer_kwargs={"betas": [0.0, 0.9]},
             lr=2e-4, device="cuda", mixed_precision=not args.fp32, channels_last=True, grad_accum=accum,
-            hip_graph=not args.no_graph, graph_warmup=1,
+            hip_graph=not args.no_graph, graph_warmup=1, bulk_noise=True,
         )
     return cfg, Trainer(cfg, device, world), local // accum
 

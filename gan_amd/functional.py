@@ -239,6 +239,32 @@ def raw_chan_dot(A: Tensor, B: Optional[Tensor], b_mode: int, ymask: Optional[Te
     return out
 
 
+# ---- all Noise draws of a generator pass from one launch -----------------------------------------------------------
+# The reference draws torch.randn(N, 1, H, W) in every Noise layer (stylegan.py:26): 13 launches of ~5 us per generator
+# pass at 256 x 256.  Inside `bulk_noise(...)` the layers take consecutive slices of ONE draw instead (the same
+# distribution; a different walk through the generator's random stream, so runs that replay recorded draws keep it off).
+_NOISE_POOL = {"buf": None, "cursor": 0}
+
+
+@contextlib.contextmanager
+def bulk_noise(total: int, device, dtype):
+    prev = dict(_NOISE_POOL)
+    _NOISE_POOL["buf"], _NOISE_POOL["cursor"] = torch.randn(total, device=device, dtype=dtype), 0
+    try:
+        yield
+    finally:
+        _NOISE_POOL.update(prev)
+
+
+def noise_draw(n: int, h: int, w: int, device, dtype) -> Tensor:
+    """torch.randn(n, 1, h, w) -- or the next n*h*w values of the active bulk draw."""
+    buf, cur, size = _NOISE_POOL["buf"], _NOISE_POOL["cursor"], n * h * w
+    if buf is not None and buf.dtype == dtype and buf.device == device and cur + size <= buf.numel() and (cur * buf.element_size()) % 16 == 0:
+        _NOISE_POOL["cursor"] = cur + size + ((-size) % 8)
+        return buf[cur : cur + size].view(n, 1, h, w)
+    return torch.randn(n, 1, h, w, device=device, dtype=dtype)
+
+
 # ---- one memset for the accumulation targets of a whole backward pass ------------------------------------------
 # gan_modconv_bwd_pre / gan_scale_dot add their workgroups' partial sums into small (N, C)-sized buffers that must
 # start at zero: a memset launch per call, ~33 per generator backward.  Inside `zeroed_scratch(device)` those buffers

@@ -228,7 +228,7 @@ class StyleGan2GeneratorBlock(nn.Module):
                 n, _, h, w = x.shape
                 ho, wo = (2 * h, 2 * w) if up2 else (h, w)
                 # one draw per Noise forward, same shape/dtype/order as the reference (stylegan.py:26)
-                draw = torch.randn(n, 1, ho, wo, device=x.device, dtype=x.dtype)
+                draw = GF.noise_draw(n, ho, wo, x.device, x.dtype)
                 x = conv.fused(x, w_embs, draw, noise_mod.scale, act.negative_slope, up2)
                 i += 3
             elif (
@@ -242,7 +242,7 @@ class StyleGan2GeneratorBlock(nn.Module):
                 blur, noise_mod, act = layers[i + 1], layers[i + 2], layers[i + 3]
                 x = blur(conv.fused(x, w_embs, None, None, 1.0, up2))
                 n, _, ho, wo = x.shape
-                draw = torch.randn(n, 1, ho, wo, device=x.device, dtype=x.dtype)
+                draw = GF.noise_draw(n, ho, wo, x.device, x.dtype)
                 x = GF.affine_act(x, noise=draw, ns=noise_mod.scale, slope=act.negative_slope)
                 i += 4
             else:  # unfused fallback for a re-arranged ModuleList: same ops, one launch each
@@ -301,6 +301,14 @@ class StyleGan2Generator(nn.Module):
         self._all_styles(w)
         dt = GF.act_dtype(z)
         x = self.learned_input.to(dt).expand(z.shape[0], -1, -1, -1)
+        if getattr(self, "bulk_noise", False) and z.is_cuda:
+            # every Noise layer's draw as a slice of one launch (opt-in: the order of the random stream changes)
+            per_sample = sum((4 * 2 ** i) ** 2 * sum(isinstance(m, Noise) for m in block.layers) for i, block in enumerate(self.blocks))
+            with GF.bulk_noise(z.shape[0] * (per_sample + 8 * len(self.blocks) * 2), z.device, dt):
+                return self._synthesis(x, w)
+        return self._synthesis(x, w)
+
+    def _synthesis(self, x: Tensor, w: Tensor) -> Tensor:
         x, y = self.blocks[0](x, w)
         for block in self.blocks[1:]:
             x, new_y = block(x, w)

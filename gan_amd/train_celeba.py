@@ -56,6 +56,9 @@ class TrainConfig:
     # MI355X-side knobs (no counterpart in the reference's TrainConfig): replay the iteration as one HIP graph
     hip_graph: bool = False
     graph_warmup: int = 3
+    # all Noise draws of a generator pass from one torch.randn launch (the same distribution, another walk through the
+    # random stream than the reference's one draw per layer, stylegan.py:26)
+    bulk_noise: bool = False
 
 
 def _fix_betas(kwargs: dict) -> dict:
@@ -87,6 +90,7 @@ class Trainer:
         # gradient arenas + bucketed all-reduce (single process: the hooks are inert, arenas still used)
         self.red_d = GradBucketReducer(self.disc)
         self.red_g = GradBucketReducer(self.gen)
+        self.gen.bulk_noise = bool(cfg.bulk_noise)  # (read by StyleGan2Generator.forward; other generators ignore it)
         self.gen_ema = EMA(self.gen)
         self.criterion = get_loss(cfg.method)
         self.regularizer = get_regularizer(cfg.regularizer)

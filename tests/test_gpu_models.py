@@ -715,3 +715,50 @@ def test_trainer_runs_stylegan_v1_recipe(dev):
         logs = tr.train_step(lambda: reals.clone())
     assert tr._graph is not None
     assert all(bool(torch.isfinite(v).all()) for v in logs.values()), logs
+
+
+@pytest.mark.gpu
+def test_generator_bulk_noise_matches_per_layer_draws(monkeypatch):
+    """StyleGan2Generator.bulk_noise: the Noise layers take consecutive slices of one draw.  Fed the same values layer by
+    layer (torch.randn patched to hand out those slices), the per-layer path produces the same image bit for bit; the
+    slices are exactly the (N, 1, H, W) draws the reference makes (stylegan.py:26), in its order."""
+    import gan_amd.functional as GF
+    from gan_amd.modelling import build_generator
+
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    gen = build_generator("stylegan2", img_size=32, base_dim=64).to(dev)
+    for m in gen.modules():
+        if type(m).__name__ == "Noise":
+            torch.nn.init.normal_(m.scale, std=0.5)  # (zero at init: the draws would not matter)
+    z = torch.randn(4, 128, device=dev)
+    real_randn = torch.randn
+    drawn = []
+
+    def spy(*shape, **kw):
+        out = real_randn(*shape, **kw)
+        drawn.append(out)
+        return out
+
+    monkeypatch.setattr(torch, "randn", spy)
+    gen.bulk_noise = True
+    with torch.no_grad():
+        img_bulk = gen(z)
+    assert len(drawn) == 1 and drawn[0].dim() == 1  # one launch for the whole pass
+    pool, cursor, shapes = drawn[0], [0], []
+
+    def replay(*shape, **kw):
+        n, _, h, w = shape
+        size = n * h * w
+        out = pool[cursor[0] : cursor[0] + size].view(n, 1, h, w).to(kw.get("dtype") or pool.dtype)
+        cursor[0] += size + ((-size) % 8)
+        shapes.append((h, w))
+        return out
+
+    monkeypatch.setattr(torch, "randn", replay)
+    gen.bulk_noise = False
+    with torch.no_grad():
+        img_layers = gen(z)
+    monkeypatch.setattr(torch, "randn", real_randn)
+    assert shapes == [(4, 4), (8, 8), (8, 8), (16, 16), (16, 16), (32, 32), (32, 32)]
+    assert torch.equal(img_bulk, img_layers)
