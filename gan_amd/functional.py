@@ -605,9 +605,13 @@ def prepack_weights(weights) -> bool:
     gkey = tuple(id(w) for w in weights)
     sig = tuple((id(w), w.data_ptr(), dt, mf, mt, q) for w, dt, mf, mt, q in plan)
     group = _PREPACK_GROUPS.get(gkey)
+    if group is not None and not all(r() is w for r, w in zip(group["keep"], weights)):
+        group = None  # ids recycled by other tensors
     if group is None or group["sig"] != sig:
         if torch.cuda.is_current_stream_capturing():
             return False
+        for k in [k for k, g in _PREPACK_GROUPS.items() if any(r() is None for r in g["keep"])]:
+            del _PREPACK_GROUPS[k]  # a group whose weights are gone: free its images
         if len(_PREPACK_GROUPS) > 64:
             _PREPACK_GROUPS.clear()
         dev = weights[0].device
@@ -636,7 +640,7 @@ def prepack_weights(weights) -> bool:
             tab["blocks"] += -(-max(cout, row[10]) // 64) * -(-max(cin, row[8]) // 64)  # 64 x 64 (co x ci) tiles
             tab["taps"] = max(tab["taps"], taps)
             tab["rows"].append(row)
-            entries.append((w, dt, mf, mt, img_f, img_t, wsq))
+            entries.append((weakref.ref(w), dt, mf, mt, img_f, img_t, wsq))
         for tab in launches.values():
             tab["table"] = torch.tensor(tab["rows"], dtype=torch.int64, device=dev)
         group = _PREPACK_GROUPS[gkey] = {"sig": sig, "launches": launches, "entries": entries, "keep": [weakref.ref(w) for w in weights]}
@@ -644,8 +648,9 @@ def prepack_weights(weights) -> bool:
     for (wdt, odt), tab in group["launches"].items():
         check(lib.gan_pack_weights_multi(ptr(tab["table"]), len(tab["rows"]), tab["blocks"], tab["taps"], _DT_CODE[wdt], _DT_CODE[odt],
                                          stream_of(tab["table"])), "gan_pack_weights_multi")
-    for w, dt, mf, mt, img_f, img_t, wsq in group["entries"]:
-        ref, ver = weakref.ref(w), (w._version, w.data_ptr())
+    for ref, dt, mf, mt, img_f, img_t, wsq in group["entries"]:
+        w = ref()  # (alive: it is one of `weights`)
+        ver = (w._version, w.data_ptr())
         if img_f is not None:
             _PACK_CACHE[(id(w), dt, mf, False)] = (ref, ver, img_f)
         if img_t is not None:
