@@ -81,7 +81,7 @@ _SIGNATURES = {
     "gan_diffaug_workspace": (c_int64, [c_int]),
     "gan_diffaug": (c_int, [c_void_p] + [c_int64] * 4 + [c_void_p] * 3 + [c_int] * 5 + [c_void_p, c_int64, c_int, c_void_p]),
     "gan_rgb_conv1x1_wgrad_workspace": (c_int64, [c_int, c_int]),
-    "gan_rgb_conv1x1_wgrad": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int64, c_int64, c_void_p, c_int, c_void_p, c_void_p, c_int64] + [c_int] * 5 + [c_void_p]),
+    "gan_rgb_conv1x1_wgrad": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int64, c_int64, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int64] + [c_int] * 5 + [c_void_p]),
     "gan_ema_lerp": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_void_p]),
     "gan_adam_step": (c_int, [c_void_p] * 4 + [c_int64, c_void_p, c_int] + [c_float] * 5 + [c_int, c_void_p]),
 }

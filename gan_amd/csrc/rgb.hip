@@ -142,7 +142,11 @@ __global__ void __launch_bounds__(RTPB) rgb_dgrad_k(const T* __restrict__ gy, co
 // partial sums for ONE 8-channel chunk of Cout (blockIdx.y), folded over the workgroup with shuffles + LDS.
 template <typename TX, typename TG>
 __global__ void __launch_bounds__(RTPB) rgb_wgrad_k(const TX* __restrict__ x, int64_t sn, int64_t sc, int64_t sh, int64_t sw, unsigned W, int lin,
-                                                    const TG* __restrict__ gy, float* __restrict__ ws, unsigned NP, unsigned HW, int Cin, int Cout) {
+                                                    const TG* __restrict__ gy, float* __restrict__ ws, unsigned NP, unsigned HW, int Cin, int Cout,
+                                                    int want_bias) {
+    // want_bias: the free channel slot Cin (< RGB_MAXC) carries a constant 1, so column Cin of the result is sum(gy): the
+    // bias gradient out of the products the kernel forms anyway (rows of ws are then Cin + 1 wide)
+    const int CW = Cin + want_bias;
     __shared__ float red[RTPB / 64][8 * RGB_MAXC];
     const int c8 = blockIdx.y * 8;
     float acc[8][RGB_MAXC];
@@ -155,7 +159,7 @@ __global__ void __launch_bounds__(RTPB) rgb_wgrad_k(const TX* __restrict__ x, in
         const TX* __restrict__ xp = x + rgb_xoff(n, p, sn, sh, sw, W, lin);
         float xv[RGB_MAXC];
 #pragma unroll
-        for (int c = 0; c < RGB_MAXC; ++c) xv[c] = c < Cin ? ldf(xp + c * sc) : 0.f;
+        for (int c = 0; c < RGB_MAXC; ++c) xv[c] = c < Cin ? ldf(xp + c * sc) : (c == Cin && want_bias ? 1.f : 0.f);
         float g[8];
         if constexpr (sizeof(TG) == 2) {
             load_f<TG, 8>(gy + (int64_t)pix * Cout + c8, g);
@@ -185,17 +189,22 @@ __global__ void __launch_bounds__(RTPB) rgb_wgrad_k(const TX* __restrict__ x, in
         float t = 0.f;
         for (int wv = 0; wv < RTPB / 64; ++wv) t += red[wv][threadIdx.x];
         const int j = threadIdx.x / RGB_MAXC, c = threadIdx.x % RGB_MAXC;
-        if (c < Cin) ws[((int64_t)blockIdx.x * Cout + c8 + j) * Cin + c] = t;
+        if (c < CW) ws[((int64_t)blockIdx.x * Cout + c8 + j) * CW + c] = t;
     }
 }
 
 // stage 2: dw[co][c] = sum over the partials of the nb workgroups (deterministic order)
-__global__ void __launch_bounds__(64) rgb_wgrad_fold_k(const float* __restrict__ ws, float* __restrict__ dw, int nb, int L) {
-    const int e = blockIdx.x;  // one wave per element
+__global__ void __launch_bounds__(64) rgb_wgrad_fold_k(const float* __restrict__ ws, float* __restrict__ dw, float* __restrict__ dbias, int nb, int L,
+                                                       int Cin, int CW) {
+    const int e = blockIdx.x;  // one wave per element of the (Cout, CW) partial rows
     float t = 0.f;
     for (int b = threadIdx.x; b < nb; b += 64) t += ws[(int64_t)b * L + e];
     for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off);
-    if (threadIdx.x == 0) dw[e] = t;
+    if (threadIdx.x == 0) {
+        const int co = e / CW, c = e - co * CW;
+        if (c < Cin) dw[co * Cin + c] = t;
+        else dbias[co] = t;
+    }
 }
 
 bool rgb_shape_ok(int Cin, int Cout) { return Cin >= 1 && Cin <= RGB_MAXC && Cout >= 8 && Cout <= 64 && (Cout & 7) == 0; }
@@ -262,19 +271,22 @@ extern "C" int gan_rgb_conv1x1_dgrad(const void* gy, const float* w, void* gx, i
     return GAN_OK;
 }
 
-extern "C" int64_t gan_rgb_conv1x1_wgrad_workspace(int Cin, int Cout) { return (int64_t)RGB_WG_BLOCKS * Cout * Cin; }
+extern "C" int64_t gan_rgb_conv1x1_wgrad_workspace(int Cin, int Cout) { return (int64_t)RGB_WG_BLOCKS * Cout * (Cin + 1); }
 
 extern "C" int gan_rgb_conv1x1_wgrad(const void* x, int x_dtype, int64_t sn, int64_t sc, int64_t sh, int64_t sw, const void* gy, int gy_dtype,
-                                     float* dw, float* workspace, int64_t workspace_floats, int N, int Cin, int H, int W, int Cout,
+                                     float* dw, float* dbias, float* workspace, int64_t workspace_floats, int N, int Cin, int H, int W, int Cout,
                                      gan_stream_t stream) {
     GAN_CHECK_ARG(N >= 0 && H > 0 && W > 0, "rgb_conv1x1_wgrad: bad shape");
     GAN_CHECK_ARG(rgb_shape_ok(Cin, Cout), "rgb_conv1x1_wgrad: serves Cin <= 4 and Cout a multiple of 8 up to 64 (got %d, %d)", Cin, Cout);
     GAN_CHECK_ARG((x_dtype == GAN_F32 || x_dtype == GAN_BF16) && (gy_dtype == GAN_F32 || gy_dtype == GAN_BF16), "rgb_conv1x1_wgrad: bad dtype");
     GAN_CHECK_ARG(dw, "rgb_conv1x1_wgrad: null pointer");
+    GAN_CHECK_ARG(dbias == nullptr || Cin < RGB_MAXC, "rgb_conv1x1_wgrad: the bias gradient rides in a free channel slot (Cin <= %d)", RGB_MAXC - 1);
     hipStream_t st = (hipStream_t)stream;
-    const int L = Cout * Cin;
+    const int want_bias = dbias != nullptr, CW = Cin + want_bias;
+    const int L = Cout * CW;
     if (N == 0) {
-        if (hipMemsetAsync(dw, 0, sizeof(float) * (size_t)L, st) != hipSuccess) {
+        if ((dbias && hipMemsetAsync(dbias, 0, sizeof(float) * (size_t)Cout, st) != hipSuccess) ||
+            hipMemsetAsync(dw, 0, sizeof(float) * (size_t)Cout * Cin, st) != hipSuccess) {
             gan_set_error("rgb_conv1x1_wgrad: memset failed");
             return GAN_ERR_LAUNCH;
         }
@@ -290,14 +302,14 @@ extern "C" int gan_rgb_conv1x1_wgrad(const void* x, int x_dtype, int64_t sn, int
     GAN_CHECK_ARG(NP < (1LL << 31), "rgb_conv1x1_wgrad: tensor too large");
     const int lin = sh == (int64_t)W * sw;
 #define RGB_WG(TX, TG) \
-    hipLaunchKernelGGL((rgb_wgrad_k<TX, TG>), grid, dim3(RTPB), 0, st, (const TX*)x, sn, sc, sh, sw, (unsigned)W, lin, (const TG*)gy, workspace, (unsigned)NP, (unsigned)(H * W), Cin, Cout)
+    hipLaunchKernelGGL((rgb_wgrad_k<TX, TG>), grid, dim3(RTPB), 0, st, (const TX*)x, sn, sc, sh, sw, (unsigned)W, lin, (const TG*)gy, workspace, (unsigned)NP, (unsigned)(H * W), Cin, Cout, want_bias)
     if (x_dtype == GAN_F32 && gy_dtype == GAN_F32) RGB_WG(float, float);
     else if (x_dtype == GAN_F32) RGB_WG(float, bf16);
     else if (gy_dtype == GAN_F32) RGB_WG(bf16, float);
     else RGB_WG(bf16, bf16);
 #undef RGB_WG
     GAN_CHECK_LAUNCH("rgb_conv1x1_wgrad");
-    hipLaunchKernelGGL(rgb_wgrad_fold_k, dim3((unsigned)L), dim3(64), 0, st, workspace, dw, (int)nb, L);
+    hipLaunchKernelGGL(rgb_wgrad_fold_k, dim3((unsigned)L), dim3(64), 0, st, workspace, dw, dbias, (int)nb, L, Cin, CW);
     GAN_CHECK_LAUNCH("rgb_conv1x1_wgrad(fold)");
     return GAN_OK;
 }

@@ -1655,7 +1655,8 @@ def _raw_rgb_dgrad(gy: Tensor, weight: Tensor) -> Tensor:
     return gx
 
 
-def _raw_rgb_wgrad(x: Tensor, gy: Tensor) -> Tensor:
+def _raw_rgb_wgrad(x: Tensor, gy: Tensor, bias: bool = False):
+    """dW (Cout, Cin, 1, 1) fp32; bias: -> (dW, dbias (Cout,)) from the same pass (Cin <= 3: a constant 1 in the free channel slot)."""
     require_gpu(x, gy)
     lib = _lib.load()
     x = x.detach()
@@ -1663,13 +1664,14 @@ def _raw_rgb_wgrad(x: Tensor, gy: Tensor) -> Tensor:
     n, cin, h, w = x.shape
     cout = gc.shape[1]
     dw = torch.empty((cout, cin, 1, 1), dtype=torch.float32, device=x.device)
+    db = torch.empty((cout,), dtype=torch.float32, device=x.device) if bias else None
     ws_floats = lib.gan_rgb_conv1x1_wgrad_workspace(cin, cout)
     ws = torch.empty((ws_floats,), dtype=torch.float32, device=x.device)
     sn, sc, sh, sw = x.stride()
     check(_run("rgb_conv1x1_wgrad", 0, _nbytes(x, gc),
-               lambda: lib.gan_rgb_conv1x1_wgrad(ptr(x), dtype_code(x), sn, sc, sh, sw, ptr(gc), dtype_code(gc), ptr(dw), ptr(ws), ws_floats, n, cin, h, w,
-                                                 cout, stream_of(x)), (n, cin, h, w, cout)), "gan_rgb_conv1x1_wgrad")
-    return dw
+               lambda: lib.gan_rgb_conv1x1_wgrad(ptr(x), dtype_code(x), sn, sc, sh, sw, ptr(gc), dtype_code(gc), ptr(dw), ptr(db), ptr(ws), ws_floats, n, cin,
+                                                 h, w, cout, stream_of(x)), (n, cin, h, w, cout)), "gan_rgb_conv1x1_wgrad")
+    return (dw, db) if bias else dw
 
 
 class RgbConvFn(Function):
@@ -1690,6 +1692,9 @@ class RgbConvFn(Function):
         x, weight, bias, y = ctx.saved_tensors
         gz = MaskMulFn.apply(gy, y, ctx.slope) if ctx.slope != 1.0 else gy
         gx = RgbDgradFn.apply(gz, weight).to(x.dtype) if _need(ctx, 0) else None
+        if _need(ctx, 1) and bias is not None and _need(ctx, 2) and not torch.is_grad_enabled() and x.shape[1] < 4:
+            gw, gb = _raw_rgb_wgrad(x, gz, bias=True)  # the bias gradient out of the weight gradient's pass over gz
+            return gx, gw.to(weight.dtype), gb.reshape(bias.shape).to(bias.dtype), None, None
         gw = RgbWgradFn.apply(x, gz).to(weight.dtype) if _need(ctx, 1) else None
         gb = ChanSumFn.apply(gz, False).reshape(bias.shape).to(bias.dtype) if bias is not None and _need(ctx, 2) else None
         return gx, gw, gb, None, None

@@ -273,14 +273,16 @@ int gan_mbstd_concat_adj(const void* g, void* gx, float* gstat, int N, int G, in
  *   fwd  : y[n][p][co] = lrelu_slope( sum_c x[n*sn + c*sc + h*sh + w*sw] * w[co][c] + bias[co] ),  y: [N][HW][Cout] (y_dtype)
  *   dgrad: gx[n][p][c] = sum_co gy[n][p][co] * w[co][c],  gx: [N][HW][Cin] in gy's dtype
  *   wgrad: dw[co][c]   = sum_{n,p} gy[n][p][co] * x[n, c, p]  (fp32; two deterministic stages through `workspace`,
- *          at least gan_rgb_conv1x1_wgrad_workspace(Cin, Cout) floats, caller-owned)
+ *          at least gan_rgb_conv1x1_wgrad_workspace(Cin, Cout) floats, caller-owned); dbias != NULL (Cin <= 3): also
+ *          dbias[co] = sum_{n,p} gy[n][p][co], the layer's bias gradient, from the same pass -- a constant 1 in the free
+ *          channel slot
  * x: element strides, fp32 or bf16; w: fp32 [Cout][Cin] (the parameter itself); Cin <= 4, Cout % 8 == 0, Cout <= 64. */
 int gan_rgb_conv1x1_fwd(const void* x, int x_dtype, int64_t sn, int64_t sc, int64_t sh, int64_t sw, const float* w, const float* bias, void* y,
                         int y_dtype, int N, int Cin, int H, int W, int Cout, float slope, gan_stream_t stream);
 int gan_rgb_conv1x1_dgrad(const void* gy, const float* w, void* gx, int64_t NP, int Cin, int Cout, int dtype, gan_stream_t stream);
 int64_t gan_rgb_conv1x1_wgrad_workspace(int Cin, int Cout);
 int gan_rgb_conv1x1_wgrad(const void* x, int x_dtype, int64_t sn, int64_t sc, int64_t sh, int64_t sw, const void* gy, int gy_dtype, float* dw,
-                          float* workspace, int64_t workspace_floats, int N, int Cin, int H, int W, int Cout, gan_stream_t stream);
+                          float* dbias, float* workspace, int64_t workspace_floats, int N, int Cin, int H, int W, int Cout, gan_stream_t stream);
 
 /* DiffAugment (diff_augment.py:13-60; train_celeba.py:63 puts it in front of the discriminator): brightness,
  * saturation, contrast, translation and cut-out of an image batch as one affine map, applied in one pass after a

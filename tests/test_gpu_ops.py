@@ -1052,6 +1052,12 @@ def test_rgb_conv1x1_family(dev, case, out_dtype, x_dtype, layout):
     xtol = 3 * TOLBF if torch.bfloat16 in (x_dtype, out_dtype) else TOL32_2  # dL/dx comes back in x's dtype
     for a, r_, nm in zip(g, gr, "xwb"):
         assert rel_err(a, r_) < (xtol if nm == "x" else tol2), (nm, rel_err(a, r_))
+    # a backward pass that is not recorded takes the bias gradient out of the weight gradient's kernel (Cin <= 3: a constant
+    # 1 in the free channel slot; Cin = 4 keeps the channel sum)
+    y2 = GF.RgbConvFn.apply(xg, wg, bg, 1.0, out_dtype)
+    gp = torch.autograd.grad((y2.float() * coef.to(dev)).sum(), [wg, bg])
+    for a, r_, nm in zip(gp, gr[1:], "wb"):
+        assert rel_err(a, r_) < tol2, ("plain", nm, rel_err(a, r_))
     tol2 = max(tol2, xtol)
     # second order: (|dL/dx|^2 + |dL/dW|^2) differentiated with respect to W and x
     g2 = torch.autograd.grad(g[0].float().square().sum() + g[1].square().sum(), [wg, xg])
