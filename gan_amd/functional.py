@@ -1355,6 +1355,7 @@ class SplitColsFn(Function):
 
     @staticmethod
     def forward(ctx, x, sizes):
+        require_gpu(x)
         lib = _lib.load()
         n, t = x.shape
         key = (x.device, tuple(sizes))

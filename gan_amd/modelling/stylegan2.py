@@ -172,11 +172,7 @@ class ModulatedConv2d(nn.Conv2d):
                 s = F.linear(w.float(), self.style_weight.weight, self.style_weight.bias) + 1  # (N, Cin)
             dinv = None
             if self.demodulation:
-                if s.is_cuda:
-                    dinv = GF.DemodFn.apply(s, self.weight)  # (N, Cout)
-                else:
-                    wsq = self.weight.float().square().sum(dim=(2, 3))  # (Cout, Cin)
-                    dinv = 1.0 / (s.square() @ wsq.t()).sqrt().clamp_min(1e-8)
+                dinv = GF.DemodFn.apply(s, self.weight)  # (N, Cout); raises on CPU tensors like every op here
         return s, dinv
 
     def fused(self, x: Tensor, w: Tensor, noise: Optional[Tensor], noise_scale: Optional[Tensor], slope: float, up2: bool):
@@ -287,10 +283,7 @@ class StyleGan2Generator(nn.Module):
             a_all = torch.cat([m.style_weight.weight for m in mods], 0)
             b_all = torch.cat([m.style_weight.bias for m in mods], 0)
             s_all = F.linear(w.float(), a_all, b_all) + 1
-            if s_all.is_cuda:
-                parts = GF.SplitColsFn.apply(s_all, tuple(m.in_channels for m in mods))  # one launch, not a copy per layer
-            else:
-                parts = [s.contiguous() for s in torch.split(s_all, [m.in_channels for m in mods], dim=1)]
+            parts = GF.SplitColsFn.apply(s_all, tuple(m.in_channels for m in mods))  # one launch, not a copy per layer
             for m, s in zip(mods, parts):
                 m._styles = s
 
