@@ -16,7 +16,8 @@ int gan_conv2d_fwd_thin(const void* x, const void* wt, void* y, const float* in_
     const bool d_stage = fu.in_slope != 1.f || fu.pool || fu.aux || fu.gain != 1.f || fu.resid;
     if (g_stage && d_stage) return 0;  // no caller mixes them; the implicit-GEMM kernel takes every combination
     if (fu.pool && fu.aux) return 0;
-    if (fu.resid && (!fu.aux || ((uintptr_t)fu.resid % 8) != 0 || (Cout & 3))) return 0;  // the residual rides in the mask mode only
+    // the residual rides in the mask mode (input gradients) and in the pooled mode (the D block's residual merge)
+    if (fu.resid && ((!fu.aux && !fu.pool) || ((uintptr_t)fu.resid % 8) != 0 || (Cout & 3))) return 0;
     if ((Cout & 3) && (Cout > 16 || fu.pool)) return 0;  // 2-byte stores: to-/from-RGB widths only
     // 32-bit buffer offsets
     const int64_t xb = (int64_t)N * H * W * Cin * 2;
@@ -33,6 +34,7 @@ int gan_conv2d_fwd_thin(const void* x, const void* wt, void* y, const float* in_
     a.x_bytes = (unsigned)xb; a.y_bytes = (unsigned)yb;
     int rc;
     if (g_stage) rc = thin_launch_g(a, Cin, kh, st);
+    else if (fu.pool && fu.resid) rc = thin_launch_dpr(a, Cin, kh, st);
     else if (fu.pool) rc = thin_launch_dp(a, Cin, kh, st);
     else if (fu.aux) rc = thin_launch_da(a, Cin, kh, st);
     else rc = thin_launch_d(a, Cin, kh, st);

@@ -35,6 +35,8 @@ enum ThinMode {
     THIN_D = 1,   // in_slope, bias, slope, gain                        (LeakyReLU -> Conv2d, progressive_gan.py:45-48)
     THIN_DA = 2,  // THIN_D + leaky-ReLU mask of `aux` on the result, + resid  (input gradients of the above)
     THIN_DP = 3,  // THIN_D + 2x2 average pooling of the result         (LeakyReLU -> Conv2d -> AvgPool2d, :48-50)
+    THIN_DPR = 4, // THIN_DP + resid (pooled resolution) added last: the block's `shortcut + layers * scale` (:54) with the
+                  // scale folded into the weights, so the residual merge costs no pass of its own
 };
 
 struct ThinArgs {
@@ -57,6 +59,7 @@ int thin_launch_g(const ThinArgs& a, int Cin, int ks, hipStream_t st);
 int thin_launch_d(const ThinArgs& a, int Cin, int ks, hipStream_t st);
 int thin_launch_da(const ThinArgs& a, int Cin, int ks, hipStream_t st);
 int thin_launch_dp(const ThinArgs& a, int Cin, int ks, hipStream_t st);
+int thin_launch_dpr(const ThinArgs& a, int Cin, int ks, hipStream_t st);
 
 #ifdef THIN_MODE
 namespace {
@@ -94,7 +97,7 @@ __global__ void __launch_bounds__(256, 2) conv_thin_k(const ThinArgs p) {
     typedef ThinCfg<CIN, COUT, KS, RPW> C;
     constexpr int CP = C::CP, TH = C::TH, HWD = C::HWD, NPIX = C::NPIX, PLANE = C::PLANE;
     constexpr int NSTEP = C::NSTEP, KPAD = C::KPAD, FCO = C::FCO, FPX = C::FPX, NLD = C::NLD;
-    constexpr bool G = MODE == THIN_G, AUX = MODE == THIN_DA, POOL = MODE == THIN_DP;
+    constexpr bool G = MODE == THIN_G, AUX = MODE == THIN_DA, POOL = MODE == THIN_DP || MODE == THIN_DPR, RES = MODE == THIN_DPR;
 
     __shared__ __attribute__((aligned(256))) char lds[C::LDS_BYTES];
     char* const xl = lds;
@@ -125,7 +128,7 @@ __global__ void __launch_bounds__(256, 2) conv_thin_k(const ThinArgs p) {
     const __amdgpu_buffer_rsrc_t rx = thin_rsrc(p.x, p.x_bytes);
     const __amdgpu_buffer_rsrc_t ry = thin_rsrc(p.y, p.y_bytes);
     const __amdgpu_buffer_rsrc_t raux = thin_rsrc(AUX ? p.fu.aux : nullptr, p.y_bytes);
-    const __amdgpu_buffer_rsrc_t rres = thin_rsrc(AUX ? p.fu.resid : nullptr, p.y_bytes);
+    const __amdgpu_buffer_rsrc_t rres = thin_rsrc((AUX || RES) ? p.fu.resid : nullptr, p.y_bytes);
     const __amdgpu_buffer_rsrc_t rnoise = thin_rsrc(G ? p.noise : nullptr, p.Cout ? p.y_bytes / (unsigned)p.Cout : 0u);
     const __amdgpu_buffer_rsrc_t rosc = thin_rsrc(G ? p.out_scale : nullptr, (unsigned)(p.N * p.Cout) * 4u);
     const __amdgpu_buffer_rsrc_t rsty = thin_rsrc(G ? p.in_scale : nullptr, (unsigned)(p.N * CIN) * 4u);
@@ -242,7 +245,7 @@ __global__ void __launch_bounds__(256, 2) conv_thin_k(const ThinArgs p) {
         const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
         constexpr int NE = POOL ? RPW : FPX;
         // batches of EB slots: first the batch's per-pixel loads (noise / mask), then its stores
-        constexpr int EB = (G || AUX) ? (FCO >= 4 ? 1 : (4 / FCO < NE ? 4 / FCO : NE)) : NE;
+        constexpr int EB = (G || AUX || RES) ? (FCO >= 4 ? 1 : (4 / FCO < NE ? 4 / FCO : NE)) : NE;
 #pragma unroll
         for (int e0 = 0; e0 < NE; e0 += EB) {
             float nz[EB];
@@ -275,6 +278,13 @@ __global__ void __launch_bounds__(256, 2) conv_thin_k(const ThinArgs p) {
                     for (int i = 0; i < FCO; ++i) {
                         const int co0 = i * 16 + kg * 4;
                         ax[k][i] = __builtin_amdgcn_raw_buffer_load_b64(raux, (live && co0 < p.Cout) ? mo[k] + co0 * 2 : THIN_INV, 0, 0);
+                        rs[k][i] = __builtin_amdgcn_raw_buffer_load_b64(rres, (live && co0 < p.Cout) ? mo[k] + co0 * 2 : THIN_INV, 0, 0);
+                    }
+                }
+                if (RES) {
+#pragma unroll
+                    for (int i = 0; i < FCO; ++i) {
+                        const int co0 = i * 16 + kg * 4;
                         rs[k][i] = __builtin_amdgcn_raw_buffer_load_b64(rres, (live && co0 < p.Cout) ? mo[k] + co0 * 2 : THIN_INV, 0, 0);
                     }
                 }
@@ -315,6 +325,11 @@ __global__ void __launch_bounds__(256, 2) conv_thin_k(const ThinArgs p) {
                         const bf16x4 a4 = __builtin_bit_cast(bf16x4, ax[k][i]), r4 = __builtin_bit_cast(bf16x4, rs[k][i]);
 #pragma unroll
                         for (int j = 0; j < 4; ++j) v[j] = fmaf(v[j], lrelu_mask((float)a4[j], p.fu.aux_slope), (float)r4[j]);  // resid: zeros if absent
+                    }
+                    if (RES) {
+                        const bf16x4 r4 = __builtin_bit_cast(bf16x4, rs[k][i]);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] += (float)r4[j];
                     }
                     bf16x4 o;
 #pragma unroll
@@ -362,7 +377,7 @@ int launch_thin_v(ThinArgs a, hipStream_t st) {
 template <int CIN, int COUT, int KS, int RPW>
 int launch_thin(const ThinArgs& a, hipStream_t st) {
     if ((a.Cout & 3) == 0) return launch_thin_v<CIN, COUT, KS, RPW, true>(a, st);
-    if constexpr (COUT == 16 && THIN_MODE != THIN_DP) return launch_thin_v<CIN, COUT, KS, RPW, false>(a, st);
+    if constexpr (COUT == 16 && THIN_MODE != THIN_DP && THIN_MODE != THIN_DPR) return launch_thin_v<CIN, COUT, KS, RPW, false>(a, st);
     gan_set_error("conv2d_fwd(thin): Cout=%d not served", a.Cout);  // the dispatcher filters these shapes
     return GAN_ERR_ARG;
 }
@@ -385,7 +400,7 @@ int pick_cin(const ThinArgs& a, int Cin, hipStream_t st) {
             // tiles bring that to 67 KB = two per CU (their load and MFMA phases overlap).  Cout = 64 stays at 8 rows: its
             // 74 KB weight image alone pins it to one workgroup per CU either way.
             // (not the pooled mode: a wave pools the row pair it owns)
-            if constexpr (KS == 3 && THIN_MODE != THIN_DP) {
+            if constexpr (KS == 3 && THIN_MODE != THIN_DP && THIN_MODE != THIN_DPR) {
                 if (a.Cout <= 32 && getenv("GAN_AMD_THIN64_RPW2") == nullptr) return pick_cout<64, KS, 1>(a, st);
             }
             return pick_cout<64, KS, 2>(a, st);

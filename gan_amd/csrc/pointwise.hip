@@ -542,6 +542,7 @@ extern "C" int gan_chan_dot(const void* A, const void* B, int b_mode, const void
     }
     GAN_CHECK_ARG(workspace != nullptr && workspace_floats >= gan_chan_dot_workspace(N, HW, C, dtype),
                   "chan_dot: needs a workspace of gan_chan_dot_workspace(...) = %lld floats", (long long)gan_chan_dot_workspace(N, HW, C, dtype));
+    GAN_CHECK_ARG(((uintptr_t)workspace % 16) == 0, "chan_dot: the workspace must be 16-byte aligned (the fold reads it with 16-byte loads)");
     if (dtype == GAN_F32) return chan_dot_launch<float>(A, B, b_mode, ymask, slope, out, out_stride_n, N, HW, C, workspace, accumulate, st);
     return chan_dot_launch<bf16>(A, B, b_mode, ymask, slope, out, out_stride_n, N, HW, C, workspace, accumulate, st);
 }
@@ -1128,6 +1129,78 @@ extern "C" int gan_space_to_depth(const void* x, void* out, int N, int H, int W,
         else hipLaunchKernelGGL((s2d_k<bf16, 1>), dim3((unsigned)blocks), dim3(TPB), 0, st, (const bf16*)x, (bf16*)out, H, W, C, Hb, Wb, pad, total, to_depth);
     }
     GAN_CHECK_LAUNCH("space_to_depth");
+    return GAN_OK;
+}
+
+// =========================================================================================
+// Convolution parameters scaled per output channel (reference: progressive_gan.py:54,
+// `shortcut(x) + layers(x) * scale`): conv(x, W) * scale + b * scale = conv(x, W * scale) + b * scale, so the
+// residual merge of a discriminator block needs no pass over the activations -- only these weight-sized maps.
+//   forward   ws[r][:] = w[r][:] * s[r],  bs[r] = b[r] * s[r]
+//   adjoint   gw[r][:] (+)= gws[r][:] * s[r],  gb[r] (+)= gbs[r] * s[r],  gs[r] (+)= sum_c gws[r][c] * w[r][c] + gbs[r] * b[r]
+// One workgroup per row, fixed summation order (deterministic).
+// =========================================================================================
+__global__ void __launch_bounds__(TPB) scale_rows_k(const float* __restrict__ w, const float* __restrict__ b, const float* __restrict__ s,
+                                                    float* __restrict__ ws, float* __restrict__ bs, int64_t cols) {
+    const int r = blockIdx.x;
+    const float sr = s[r];
+    const float* __restrict__ wr = w + (int64_t)r * cols;
+    float* __restrict__ wo = ws + (int64_t)r * cols;
+    for (int64_t c = threadIdx.x; c < cols; c += TPB) wo[c] = wr[c] * sr;
+    if (threadIdx.x == 0 && bs) bs[r] = b[r] * sr;
+}
+
+__global__ void __launch_bounds__(TPB) scale_rows_bwd_k(const float* __restrict__ gws, const float* __restrict__ gbs, const float* __restrict__ w,
+                                                        const float* __restrict__ b, const float* __restrict__ s, float* __restrict__ gw, int acc_w,
+                                                        float* __restrict__ gb, int acc_b, float* __restrict__ gs, int acc_s, int64_t cols) {
+    __shared__ float red[TPB / 64];
+    const int r = blockIdx.x;
+    const float sr = s[r];
+    float dot = 0.f;
+    if (gws) {
+        const float* __restrict__ gr = gws + (int64_t)r * cols;
+        const float* __restrict__ wr = w + (int64_t)r * cols;
+        float* __restrict__ go = gw ? gw + (int64_t)r * cols : nullptr;
+        for (int64_t c = threadIdx.x; c < cols; c += TPB) {
+            const float g = gr[c];
+            dot = fmaf(g, wr[c], dot);
+            if (go) go[c] = acc_w ? fmaf(g, sr, go[c]) : g * sr;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) dot += __shfl_xor(dot, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dot;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < TPB / 64; ++k) t += red[k];
+        const float gbr = gbs ? gbs[r] : 0.f;
+        if (gbs && b) t = fmaf(gbr, b[r], t);
+        if (gs) gs[r] = acc_s ? gs[r] + t : t;
+        if (gb && gbs) gb[r] = acc_b ? fmaf(gbr, sr, gb[r]) : gbr * sr;
+    }
+}
+
+extern "C" int gan_scale_rows(const float* w, const float* b, const float* s, float* ws, float* bs, int rows, int64_t cols, gan_stream_t stream) {
+    GAN_CHECK_ARG(rows >= 0 && cols >= 0, "scale_rows: bad shape");
+    if (rows == 0) return GAN_OK;
+    GAN_CHECK_ARG(w && s && ws, "scale_rows: null pointer");
+    GAN_CHECK_ARG((b == nullptr) == (bs == nullptr), "scale_rows: b and bs go together");
+    hipLaunchKernelGGL(scale_rows_k, dim3((unsigned)rows), dim3(TPB), 0, (hipStream_t)stream, w, b, s, ws, bs, cols);
+    GAN_CHECK_LAUNCH("scale_rows");
+    return GAN_OK;
+}
+
+extern "C" int gan_scale_rows_bwd(const float* gws, const float* gbs, const float* w, const float* b, const float* s, float* gw, int acc_w,
+                                  float* gb, int acc_b, float* gs, int acc_s, int rows, int64_t cols, gan_stream_t stream) {
+    GAN_CHECK_ARG(rows >= 0 && cols >= 0, "scale_rows_bwd: bad shape");
+    if (rows == 0) return GAN_OK;
+    GAN_CHECK_ARG(s && (gws == nullptr || w != nullptr), "scale_rows_bwd: null pointer");
+    GAN_CHECK_ARG(gbs == nullptr || b != nullptr, "scale_rows_bwd: gbs needs b");
+    hipLaunchKernelGGL(scale_rows_bwd_k, dim3((unsigned)rows), dim3(TPB), 0, (hipStream_t)stream, gws, gbs, w, b, s, gw, acc_w, gb, acc_b, gs,
+                       acc_s, cols);
+    GAN_CHECK_LAUNCH("scale_rows_bwd");
     return GAN_OK;
 }
 

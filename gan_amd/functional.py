@@ -273,6 +273,15 @@ def noise_draw(n: int, h: int, w: int, device, dtype) -> Tensor:
 _ZERO_POOL: dict = {}
 
 
+def _grow_pool(st: dict, device) -> None:
+    """A larger pool buffer.  The old one is retired, not freed: a captured HIP graph may have its address baked into a
+    memset and into the accumulating kernels, and the caching allocator would hand freed memory to someone else while
+    replays keep writing into it.  (The pools are a few hundred KB; they grow a handful of times per process.)"""
+    if st["buf"] is not None:
+        st.setdefault("retired", []).append(st["buf"])
+    st["buf"] = torch.empty((st["want"] + st["want"] // 4 + 4096,), dtype=torch.float32, device=device)
+
+
 @contextlib.contextmanager
 def zeroed_scratch(device):
     device = torch.device(device)
@@ -288,7 +297,7 @@ def zeroed_scratch(device):
     st["want"] = max(st["want"], st["need"])
     have = st["buf"].numel() if st["buf"] is not None else 0
     if st["want"] > have and not torch.cuda.is_current_stream_capturing():  # (an allocation made while capturing would belong to the graph)
-        st["buf"] = torch.empty((st["want"] + st["want"] // 4 + 4096,), dtype=torch.float32, device=device)
+        _grow_pool(st, device)
     if st["buf"] is not None:
         st["buf"].zero_()
     st["cursor"], st["need"], st["active"] = 0, 0, True
@@ -303,7 +312,7 @@ def grow_zero_pool() -> None:
     for device, st in _ZERO_POOL.items():
         st["want"] = max(st["want"], st["need"])
         if st["want"] > (st["buf"].numel() if st["buf"] is not None else 0) and not st["active"]:
-            st["buf"] = torch.empty((st["want"] + st["want"] // 4 + 4096,), dtype=torch.float32, device=device)
+            _grow_pool(st, device)
 
 
 def _zeroed(nfloats: int, device) -> Optional[Tensor]:
@@ -487,11 +496,11 @@ def pack_weight(weight: Tensor, dtype: torch.dtype, cin_mult: int = 8, transpose
     `transposed` packs the flipped, channel-swapped weights of the input-gradient correlation."""
     cacheable = weight.is_leaf and (weight.requires_grad or isinstance(weight, torch.nn.Parameter)) and weight.numel() > 0
     if not cacheable:
-        owner = _fold_owner(weight) if _FOLD_OWNER else None
-        if owner is None:
+        derived = _derived_owner(weight) if (_FOLD_OWNER or _SCALED_OWNER) else None
+        if derived is None:
             return _pack_weight(weight.detach(), dtype, cin_mult, transposed)
-        key = ("fold", id(owner), dtype, cin_mult, transposed)  # images of a parameter's folded copy: valid as long as the copy is
-        ver = (owner._version, owner.data_ptr())
+        kind, owner, ver = derived
+        key = (kind, id(owner), dtype, cin_mult, transposed)  # images of a parameter's folded / scaled copy: valid as long as the copy is
         hit = _PACK_CACHE.get(key)
         if hit is not None and hit[0]() is owner and hit[1] == ver:
             PACK_STATS[0] += 1
@@ -537,6 +546,8 @@ def drop_packed() -> None:
     _WSQ_CACHE.clear()
     _FOLD_CACHE.clear()
     _FOLD_OWNER.clear()
+    _SCALED_CACHE.clear()
+    _SCALED_OWNER.clear()
     _PAD_MEMO.clear()
 
 
@@ -545,13 +556,16 @@ def invalidate_packed(params) -> None:
     back -- through a flat arena or a raw pointer (EMA.step, a graph replay) -- so that neither `_version` nor
     `data_ptr()` moves and the cache key above would still match."""
     ids = {id(p) for p in params}
-    for key in [k for k in _PACK_CACHE if (k[1] if k[0] == "fold" else k[0]) in ids]:
+    for key in [k for k in _PACK_CACHE if (k[1] if isinstance(k[0], str) else k[0]) in ids]:
         del _PACK_CACHE[key]
     for i in ids:
         _WSQ_CACHE.pop(i, None)
         hit = _FOLD_CACHE.pop(i, None)
         if hit is not None:
             _FOLD_OWNER.pop(hit[2].data_ptr(), None)
+        hit = _SCALED_CACHE.pop(i, None)
+        if hit is not None:
+            _SCALED_OWNER.pop(hit[2][0].data_ptr(), None)
 
 
 # ---- all packed images of a network in one launch -----------------------------------------------------------
@@ -1474,10 +1488,13 @@ class ConvBiasActFn(Function):
     Backward = mask_mul -> dgrad / wgrad / channel sum, all differentiable again."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, pad, slope, in_slope=1.0, pool=False):
-        y = raw_conv2d(x, weight, pad, pad, bias=bias, slope=slope, in_slope=in_slope, pool=pool)
+    def forward(ctx, x, weight, bias, pad, slope, in_slope=1.0, pool=False, resid=None):
+        if resid is not None and slope != 1.0:
+            raise _lib.GanAmdError("conv_bias_act: a residual rides behind a linear output stage only (slope = 1)")
+        y = raw_conv2d(x, weight, pad, pad, bias=bias, slope=slope, in_slope=in_slope, pool=pool, resid=resid)
         ctx.save_for_backward(x, weight, bias, y if slope != 1.0 else None)
         ctx.cfg = (pad, slope, in_slope, pool)
+        ctx.resid_dtype = resid.dtype if resid is not None else None
         return y
 
     @staticmethod
@@ -1495,13 +1512,120 @@ class ConvBiasActFn(Function):
                 gw = _wgrad_for(weight, x, gz, pad, pad, in_slope, pool)
             if bias is not None and _need(ctx, 2):
                 gb = _bias_grad_for(bias, gz)
-        return gx, gw, gb, None, None, None, None
+        g_resid = gy.to(ctx.resid_dtype) if ctx.resid_dtype is not None and _need(ctx, 7) else None  # (added last: the identity)
+        return gx, gw, gb, None, None, None, None, g_resid
 
 
 def conv_bias_act(x: Tensor, weight: Tensor, bias: Optional[Tensor], padding: int, slope: float = 1.0, in_slope: float = 1.0,
-                  pool: bool = False) -> Tensor:
-    """pool: AvgPool2d(2) of the convolution result, BEFORE the bias and the activation (avg_pool(z + b) = avg_pool(z) + b)."""
-    return ConvBiasActFn.apply(x, weight, bias, padding, slope, in_slope, pool)
+                  pool: bool = False, resid: Optional[Tensor] = None) -> Tensor:
+    """pool: AvgPool2d(2) of the convolution result, BEFORE the bias and the activation (avg_pool(z + b) = avg_pool(z) + b).
+    resid: a tensor shaped like the result, added last (slope = 1 only): a residual merge without a pass of its own."""
+    return ConvBiasActFn.apply(x, weight, bias, padding, slope, in_slope, pool, resid)
+
+
+# ---- conv parameters scaled per output channel: the D block's `shortcut + layers * scale` (progressive_gan.py:54) -------
+# conv(x, W) * scale + b * scale = conv(x, W * scale) + b * scale: with the scale folded into the block's last convolution
+# and the shortcut added as that convolution's residual, the merge and its adjoints (a scale pass over the incoming
+# gradient, a channel dot product with the saved branch output -- every D pass, first and second order) cost nothing
+# activation-sized; what remains is weight-sized: one launch forward per version of the parameters, one backward.
+_SCALED_CACHE: dict = {}   # id(w) -> (weakref(w), version key, (ws, bs), version function)
+_SCALED_OWNER: dict = {}   # data_ptr of a cached ws -> weakref(w): lets pack_weight cache the GEMM images of ws
+
+
+class ScaleConvParamsFn(Function):
+    """(W (Cout, Cin, kh, kw), b (Cout,) | None, s (Cout, ...)) -> (W * s[co], b * s[co]), fp32 (kernel gan_scale_rows).
+    Backward (kernel gan_scale_rows_bwd): gW = gWs * s, gb = gbs * s, gs = rowdot(gWs, W) + gbs * b; added straight into
+    the parameters' gradient buffers under direct_param_grads().  Under create_graph: the same formulas on tensor ops
+    (weight-sized; no caller in the train step -- R1 / WGAN-GP differentiate with respect to images).
+    The node keeps the parameters on ctx (no saved-tensor slots): one cached output serves every forward pass of a
+    step (reals, fakes) and survives a backward pass."""
+
+    @staticmethod
+    def forward(ctx, w, b, s):
+        require_gpu(w, b, s)
+        lib = _lib.load()
+        if w.dtype != torch.float32 or s.dtype != torch.float32 or (b is not None and b.dtype != torch.float32) or s.numel() != w.shape[0]:
+            raise _lib.GanAmdError("scaled_conv_params: fp32 parameters, one scale per output channel")
+        wd, sd = w.detach().contiguous(), s.detach().reshape(-1).contiguous()
+        bd = b.detach().contiguous() if b is not None else None
+        ws = torch.empty_like(wd)
+        bs = torch.empty_like(bd) if bd is not None else None
+        check(lib.gan_scale_rows(ptr(wd), ptr(bd), ptr(sd), ptr(ws), ptr(bs), w.shape[0], wd.numel() // max(w.shape[0], 1), stream_of(wd)),
+              "gan_scale_rows")
+        ctx.params = (w, b, s)
+        ctx.set_materialize_grads(False)
+        if bs is None:
+            return ws, None
+        return ws, bs
+
+    @staticmethod
+    def backward(ctx, gws, gbs):
+        w, b, s = ctx.params
+        if gws is None and gbs is None:
+            return None, None, None
+        need_w, need_b, need_s = _need(ctx, 0), b is not None and _need(ctx, 1), _need(ctx, 2)
+        if torch.is_grad_enabled():
+            sv = s.reshape(-1)
+            gw = gws * sv.view(-1, 1, 1, 1) if need_w and gws is not None else None
+            gb = gbs * sv if need_b and gbs is not None else None
+            gs = None
+            if need_s:
+                gs = torch.zeros_like(sv)
+                if gws is not None:
+                    gs = gs + (gws * w).flatten(1).sum(1)
+                if gbs is not None and b is not None:
+                    gs = gs + gbs * b
+                gs = gs.reshape(s.shape)
+            return gw, gb, gs
+        lib = _lib.load()
+        rows, cols = w.shape[0], w.numel() // max(w.shape[0], 1)
+        wd, sd = w.detach().contiguous(), s.detach().reshape(-1).contiguous()
+        bd = b.detach().contiguous() if b is not None else None
+        g_w = gws.detach().float().contiguous() if gws is not None else None
+        g_b = gbs.detach().float().contiguous() if (gbs is not None and b is not None) else None
+        wslot = grad_slot(w) if need_w and g_w is not None else None
+        bslot = grad_slot(b) if need_b and g_b is not None else None
+        sslot = grad_slot(s) if need_s else None
+        for p_ in (b, s):  # FlatArena.begin_direct: zeroed gradient slices for these from the next pass on
+            if isinstance(p_, torch.nn.Parameter):
+                p_._gan_direct = True
+        gw = wslot if wslot is not None else (torch.empty_like(wd) if need_w and g_w is not None else None)
+        gb = bslot if bslot is not None else (torch.empty_like(bd) if need_b and g_b is not None else None)
+        gs = sslot.reshape(-1) if sslot is not None else (torch.empty_like(sd) if need_s else None)
+        check(lib.gan_scale_rows_bwd(ptr(g_w), ptr(g_b), ptr(wd), ptr(bd), ptr(sd), ptr(gw), int(wslot is not None), ptr(gb), int(bslot is not None),
+                                     ptr(gs), int(sslot is not None), rows, cols, stream_of(wd)), "gan_scale_rows_bwd")
+        return (None if wslot is not None else gw), (None if bslot is not None else gb), (None if sslot is not None or gs is None else gs.reshape(s.shape))
+
+
+def scaled_conv_params(w: Tensor, b: Optional[Tensor], s: Tensor):
+    """(w * s[co], b * s[co]) for a conv weight / bias and a per-output-channel scale, computed once per version of the
+    three (cached on the weight: the reals and fakes passes of a discriminator step share one copy and its packed GEMM
+    images; an optimizer step, a graph replay or a checkpoint load drops it through invalidate_packed / drop_packed)."""
+    needs = torch.is_grad_enabled() and (w.requires_grad or s.requires_grad or (b is not None and b.requires_grad))
+    if not (isinstance(w, torch.nn.Parameter) and w.is_leaf and s.is_leaf and (b is None or b.is_leaf)):
+        ws, bs = ScaleConvParamsFn.apply(w, b, s)
+        return ws, bs
+    wr, sr, br = weakref.ref(w), weakref.ref(s), (weakref.ref(b) if b is not None else None)
+
+    def version():
+        w_, s_, b_ = wr(), sr(), (br() if br is not None else None)
+        if w_ is None or s_ is None or (br is not None and b_ is None):
+            return None
+        return (w_._version, w_.data_ptr(), s_._version, s_.data_ptr(), (b_._version, b_.data_ptr()) if b_ is not None else None, needs)
+
+    ver = version()
+    hit = _SCALED_CACHE.get(id(w))
+    if hit is not None and hit[0]() is w and hit[1] == ver:
+        return hit[2]
+    if hit is not None:
+        _SCALED_OWNER.pop(hit[2][0].data_ptr(), None)
+    if len(_SCALED_CACHE) > 1024:
+        _SCALED_CACHE.clear()
+        _SCALED_OWNER.clear()
+    out = ScaleConvParamsFn.apply(w, b, s)
+    _SCALED_CACHE[id(w)] = (wr, ver, out, version)
+    _SCALED_OWNER[out[0].data_ptr()] = wr
+    return out
 
 
 class DemodFn(Function):
@@ -1821,6 +1945,22 @@ class FoldWeightFn(Function):
     @staticmethod
     def backward(ctx, g):
         return _unfold_perm(g)
+
+
+def _derived_owner(t: Tensor):
+    """(kind, parameter, version key) when `t` aliases the current cached folded (FoldWeightFn) or scaled
+    (ScaleConvParamsFn) copy of a parameter, else None."""
+    p = _fold_owner(t) if _FOLD_OWNER else None
+    if p is not None:
+        return "fold", p, (p._version, p.data_ptr())
+    ref = _SCALED_OWNER.get(t.data_ptr())
+    p = ref() if ref is not None else None
+    if p is None:
+        return None
+    hit = _SCALED_CACHE.get(id(p))
+    if hit is None or hit[0]() is not p or hit[2][0].data_ptr() != t.data_ptr() or hit[2][0].shape != t.shape or hit[1] != hit[3]():
+        return None
+    return "scaled", p, hit[1]
 
 
 def _fold_owner(t: Tensor):

@@ -11,7 +11,7 @@ convolution that precedes it (the shortcut's pool -> 1x1 conv runs as conv -> po
 map), and the adjoints of both ride in the input-/weight-gradient kernels; conv biases that precede
 AvgPool2d are added after it (avg_pool(z + b) = avg_pool(z) + b) on the same accumulators; the residual
     out = shortcut + layers * scale
-is one pass.
+rides on the last convolution (scale folded into its parameters, shortcut as its residual input).
 LeakyReLU is applied out of place (the shipped inplace=True breaks autograd).
 """
 from __future__ import annotations
@@ -77,9 +77,16 @@ class ProgressiveGanDiscriminatorBlock(nn.Module):
         # map, in one launch) share x: one autograd node, so their input gradients come out of one kernel
         h, s = GF.DBlockInputFn.apply(x, conv1.weight, conv1.bias, conv_s.weight, act0.negative_slope, conv_s.out_channels <= 64,
                                       conv_s.bias)
-        # act -> conv2 -> pool (+ bias: avg_pool(z + b) = avg_pool(z) + b) in one launch
+        # act -> conv2 -> pool (+ bias: avg_pool(z + b) = avg_pool(z) + b) in one launch, and the residual merge
+        # shortcut + layers * scale (progressive_gan.py:54) with it: the scale is folded into conv2's parameters
+        # (conv(x, W) * scale + b * scale = conv(x, W * scale) + b * scale, weight-sized work once per version of the
+        # parameters) and the shortcut rides as the convolution's residual -- no pass over the activations, forward or
+        # backward, first or second order
+        if conv2.weight.dtype == torch.float32 and self.scale.dtype == torch.float32:
+            w2s, b2s = GF.scaled_conv_params(conv2.weight, conv2.bias, self.scale)
+            return GF.conv_bias_act(h, w2s, b2s, conv2.padding[0], 1.0, act1.negative_slope, True, s)
         h = GF.conv_bias_act(h, conv2.weight, conv2.bias, conv2.padding[0], 1.0, act1.negative_slope, True)
-        return GF.affine_act(h, a=self.scale.reshape(-1), r=s)  # shortcut + layers * scale (progressive_gan.py:54)
+        return GF.affine_act(h, a=self.scale.reshape(-1), r=s)
 
 
 class ProgressiveGanDiscriminator(nn.Sequential):

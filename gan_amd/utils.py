@@ -144,17 +144,20 @@ class FlatArena:
             torch._foreach_zero_(views)
 
     def gather_grads(self) -> None:
-        views, srcs, missing = [], [], False
+        views, srcs, missing = [], [], []
         for p, o in zip(self.params, self.offsets):
             g = p.grad
             if g is None:
-                missing = missing or p.requires_grad
+                if p.requires_grad:
+                    missing.append(self.grad[o : o + p.numel()])
                 continue
             if g.data_ptr() != self.grad.data_ptr() + 4 * o:
                 views.append(self.grad[o : o + p.numel()].view(p.shape))
                 srcs.append(g)
         if missing:
-            self.grad.zero_()  # a parameter that took no part in this pass: its slice must read zero
+            # a parameter that took no part in this pass: its slice must read zero.  Only ITS slice: the slices handed
+            # out by begin_direct() already hold the sums the kernels added in place during the pass
+            torch._foreach_zero_(missing)
         if views:
             torch._foreach_copy_(views, srcs)
         self.attach_grads()

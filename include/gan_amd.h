@@ -81,7 +81,8 @@ int gan_mask_scale(const void* g, const void* ymask, const float* a, int64_t a_s
  * kernel that sums them in a fixed order): no atomics, `out` need not be zeroed, every element of it is written.
  * accumulate = 1: out += the sums instead (a parameter's gradient buffer that other passes have already written to:
  * autograd's accumulation step, torch/csrc/autograd/functions/accumulate_grad.h, without its launch per tensor).
- * workspace: at least gan_chan_dot_workspace(N, HW, C, dtype) floats, caller-owned (the library never allocates). */
+ * workspace: at least gan_chan_dot_workspace(N, HW, C, dtype) floats, 16-byte aligned, caller-owned (the library never
+ * allocates). */
 int64_t gan_chan_dot_workspace(int N, int64_t HW, int C, int dtype);
 int gan_chan_dot(const void* A, const void* B, int b_mode, const void* ymask, float slope, float* out,
                  int64_t out_stride_n, int N, int64_t HW, int C, float* workspace, int64_t workspace_floats, int accumulate,
@@ -347,6 +348,19 @@ int gan_layernorm2d_fwd(const void* x, const float* w, const float* b, void* y, 
                         int dtype, gan_stream_t stream);
 int gan_layernorm2d_bwd(const void* g, const void* x, const void* ymask, const float* w, const float* stats, void* gx, float* gwb,
                         int64_t NP, int C, float slope, int dtype, gan_stream_t stream);
+
+/* ---- convolution parameters scaled per output channel ------------------------------------
+ * replaces the activation-sized multiply of `self.shortcut(x) + self.layers(x) * self.scale`   modelling/progressive_gan.py:54
+ * conv(x, W) * scale + b * scale = conv(x, W * scale) + b * scale: the block's last convolution runs on
+ *   ws[r][:] = w[r][:] * s[r],  bs[r] = b[r] * s[r]          (rows = Cout, cols = Cin*kh*kw; b / bs may both be NULL)
+ * and adds the shortcut as its `resid` (gan_conv2d_fwd), so the merge costs no pass over the activations.
+ * gan_scale_rows_bwd is the adjoint of that map (any of gws / gbs / gw / gb / gs may be NULL):
+ *   gw[r][:] (+)= gws[r][:] * s[r],  gb[r] (+)= gbs[r] * s[r],  gs[r] (+)= sum_c gws[r][c] * w[r][c] + gbs[r] * b[r]
+ * acc_* = 1 adds into the buffer (a parameter's gradient slice), 0 overwrites.  All fp32; one workgroup per row, fixed
+ * summation order. */
+int gan_scale_rows(const float* w, const float* b, const float* s, float* ws, float* bs, int rows, int64_t cols, gan_stream_t stream);
+int gan_scale_rows_bwd(const float* gws, const float* gbs, const float* w, const float* b, const float* s, float* gw, int acc_w,
+                       float* gb, int acc_b, float* gs, int acc_s, int rows, int64_t cols, gan_stream_t stream);
 
 /* ---- EMA ---------------------------------------------------------------------------------
  * replaces the per-parameter lerp_ loop of EMA.step   utils.py:95-96

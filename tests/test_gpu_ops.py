@@ -489,6 +489,130 @@ def test_conv2d_act_pool_second_order(dev):
     assert rel_err(hx, hx_ref) < TOL32_2 and rel_err(hw, hw_ref) < TOL32_2
 
 
+RESID_MERGE_CASES = [
+    # N, Cin, H, W, Cout: LeakyReLU -> conv3x3 -> AvgPool2d, scaled per channel, + shortcut (progressive_gan.py:45-54)
+    (2, 16, 64, 64, 32),     # thin pooled kernel with the residual (THIN_DPR), 8-row tiles
+    (3, 32, 40, 64, 64),     # ... ragged tile rows
+    (2, 64, 32, 32, 64),     # ... Cin = 64
+    (4, 64, 64, 64, 128),    # wide kernels
+    (3, 128, 16, 16, 256),
+    (5, 256, 8, 8, 512),
+    (3, 24, 6, 10, 40),      # generic kernel
+]
+
+
+@pytest.mark.parametrize("case", RESID_MERGE_CASES)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_residual_merge_on_the_convolution(dev, case, dtype):
+    """shortcut + AvgPool2d(conv(leaky_relu(h), W) + b) * scale  (progressive_gan.py:45-54) as ONE launch:
+    scaled_conv_params folds the scale into (W, b), conv_bias_act adds the shortcut as its residual.  Output and every
+    gradient (h, shortcut, W, b, scale) against the formula as written, differentiated by torch in fp64."""
+    import gan_amd.functional as GF
+
+    n, cin, h, w, cout = case
+    torch.manual_seed(61)
+    x = torch.randn(n, cin, h, w).to(dtype)
+    sc = torch.randn(n, cout, h // 2, w // 2).to(dtype)
+    wgt = torch.randn(cout, cin, 3, 3) / (cin * 9) ** 0.5
+    b = torch.randn(cout) * 0.3
+    scale = torch.randn(cout, 1, 1) * 0.5
+    cot = torch.randn(n, cout, h // 2, w // 2).to(dtype)
+    ref_in = [t.double().requires_grad_(True) for t in (x, sc, wgt, b, scale)]
+    xr, sr, wr, br, scr = ref_in
+    if dtype == torch.bfloat16:  # the kernel's operand: the scaled weight rounded to bf16
+        w_eff = (wr * scr.view(-1, 1, 1, 1)).detach().float().bfloat16().double()
+        w_eff = w_eff + (wr * scr.view(-1, 1, 1, 1) - (wr * scr.view(-1, 1, 1, 1)).detach())  # (value rounded, gradient exact)
+        y_ref = sr + F.avg_pool2d(F.conv2d(F.leaky_relu(xr, 0.2), w_eff, padding=1), 2) + (br * scr.view(-1)).view(1, -1, 1, 1)
+    else:
+        y_ref = sr + F.avg_pool2d(F.conv2d(F.leaky_relu(xr, 0.2), wr, br, padding=1), 2) * scr
+    g_ref = torch.autograd.grad((y_ref * cot.double()).sum(), ref_in)
+    got_in = [t.to(dev).requires_grad_(True) for t in (x, sc, wgt, b, scale)]
+    xg, sg, wg, bg, scg = got_in
+    ws, bs = GF.scaled_conv_params(wg, bg, scg)
+    y = GF.conv_bias_act(xg, ws, bs, 1, 1.0, 0.2, True, sg)
+    assert y.shape == y_ref.shape and y.dtype == dtype
+    tol = TOL32 if dtype == torch.float32 else 6e-3
+    assert rel_err(y, y_ref) < tol, ("fwd", rel_err(y, y_ref))
+    g = torch.autograd.grad((y * cot.to(dev)).sum(), got_in)
+    for name, a, r_ in zip(("h", "shortcut", "W", "b", "scale"), g, g_ref):
+        assert a.shape == r_.shape
+        assert rel_err(a, r_) < (tol if name != "scale" or dtype == torch.float32 else 1e-2), (name, rel_err(a, r_))
+
+
+def test_scaled_conv_params_cache_and_second_order(dev):
+    """scaled_conv_params: parameters get ONE scaled copy per version (shared by the passes of a step, re-made after an
+    in-place update or invalidate_packed), its packed GEMM images are cached with it, a cached copy survives a backward
+    pass, gradients go straight into preset gradient buffers under direct_param_grads(), and the block stays closed
+    under differentiation (R1: second order through the scaled convolution with respect to every parameter)."""
+    import gan_amd.functional as GF
+    from torch import nn
+
+    torch.manual_seed(62)
+    w = nn.Parameter(torch.randn(32, 16, 3, 3, device=dev) / 12)
+    b = nn.Parameter(torch.randn(32, device=dev) * 0.3)
+    s = nn.Parameter(torch.randn(32, 1, 1, device=dev) * 0.5)
+    a1 = GF.scaled_conv_params(w, b, s)
+    a2 = GF.scaled_conv_params(w, b, s)
+    assert a1[0] is a2[0] and a1[1] is a2[1] and a1[0].grad_fn is not None
+    assert rel_err(a1[0], w * s.view(-1, 1, 1, 1)) < 1e-6 and rel_err(a1[1], b * s.view(-1)) < 1e-6
+    with torch.no_grad():
+        n1 = GF.scaled_conv_params(w, b, s)
+    assert n1[0] is not a1[0] and n1[0].grad_fn is None
+    x = torch.randn(2, 16, 32, 32, device=dev).bfloat16()
+    sc = torch.randn(2, 32, 16, 16, device=dev).bfloat16()
+
+    def loss():
+        ws, bs = GF.scaled_conv_params(w, b, s)
+        return GF.conv_bias_act(x, ws, bs, 1, 1.0, 0.2, True, sc).float().square().mean()
+
+    GF.PACK_STATS[0] = GF.PACK_STATS[1] = 0
+    loss().backward()
+    ref = [p.grad.clone() for p in (w, b, s)]
+    misses = GF.PACK_STATS[1]
+    loss().backward()  # same cached copy (its node ran a backward pass already), same packed images
+    assert GF.PACK_STATS[1] == misses and GF.PACK_STATS[0] >= 1
+    for p, r_ in zip((w, b, s), ref):
+        assert rel_err(p.grad, 2 * r_) < 1e-5
+    # straight into the gradient buffers
+    seeds = [torch.randn_like(r_) for r_ in ref]
+    for p, sd in zip((w, b, s), seeds):
+        p.grad = sd.clone()
+    with GF.direct_param_grads():
+        loss().backward()
+    for p, sd, r_ in zip((w, b, s), seeds, ref):
+        assert rel_err(p.grad - sd, r_) < 1e-5
+    # an in-place update (an optimizer step) re-makes the copy
+    with torch.no_grad():
+        s.mul_(2.0)
+    a3 = GF.scaled_conv_params(w, b, s)
+    assert a3[0] is not a1[0] and rel_err(a3[0], w * s.view(-1, 1, 1, 1)) < 1e-6
+    GF.invalidate_packed([w])
+    assert GF.scaled_conv_params(w, b, s)[0] is not a3[0]
+
+    # second order, fp32, against torch in fp64
+    xf = torch.randn(2, 16, 8, 8)
+    scf = torch.randn(2, 32, 4, 4)
+    ref_in = [t.detach().cpu().double().requires_grad_(True) for t in (xf, w, b, s)]
+    xr, wr, br, sr = ref_in
+    y_ref = scf.double() + F.avg_pool2d(F.conv2d(F.leaky_relu(xr, 0.2), wr, br, padding=1), 2) * sr
+    (gx_ref,) = torch.autograd.grad(y_ref.square().sum(), xr, create_graph=True)
+    h_ref = torch.autograd.grad(gx_ref.square().sum(), [wr, br, sr, xr], allow_unused=True)
+    xg = xf.to(dev).requires_grad_(True)
+    for p in (w, b, s):
+        p.grad = None
+    ws, bs = GF.scaled_conv_params(w, b, s)
+    y = GF.conv_bias_act(xg, ws, bs, 1, 1.0, 0.2, True, scf.to(dev))
+    assert rel_err(y, y_ref) < TOL32
+    (gx,) = torch.autograd.grad(y.square().sum(), xg, create_graph=True)
+    assert rel_err(gx, gx_ref) < TOL32
+    hgot = torch.autograd.grad(gx.square().sum(), [w, b, s, xg], allow_unused=True)
+    for name, a, r_ in zip(("W", "b", "scale", "x"), hgot, h_ref):
+        if r_ is None:
+            assert a is None or float(a.abs().max()) == 0.0, name
+        else:
+            assert rel_err(a, r_) < TOL32_2, (name, rel_err(a, r_))
+
+
 WIDE_CASES = [
     # N, Cin, H, W, Cout, k, up2, pool   (bf16, Cin % 64 == 0, not thin: conv_wide.hip, LDS-DMA staging)
     (4, 128, 32, 32, 128, 3, False, False),
@@ -1114,6 +1238,46 @@ def test_accumulate_into_gradient_buffers(dev):
     with GF.direct_param_grads():
         (gw,) = torch.autograd.grad(loss(), conv_w, create_graph=True)
     assert torch.equal(conv_w.grad, seed_w) and rel_err(gw, ref_w) < 1e-5
+
+
+def test_direct_grads_with_an_unused_parameter(dev):
+    """FlatArena.begin_direct() + GF.direct_param_grads() + gather_grads() when one parameter takes no part in the pass:
+    only ITS slice of the gradient arena is cleared; the sums the kernels added in place into the other slices stay
+    (round 2 cleared the whole arena there).  Reference = the same pass with autograd's own accumulation."""
+    import gan_amd.functional as GF
+    from gan_amd.utils import FlatArena
+    from torch import nn
+
+    torch.manual_seed(59)
+
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = nn.Parameter(torch.randn(32, 16, 3, 3) * 0.1)
+            self.b = nn.Parameter(torch.randn(32) * 0.1)
+            self.unused = nn.Parameter(torch.randn(7))
+            self.gain = nn.Parameter(torch.randn(()))
+
+        def forward(self, x):
+            return GF.ConvBiasActFn.apply(x, self.w, self.b, 1, 0.2).float().square().mean() * self.gain
+
+    net = Net().to(dev)
+    x = torch.randn(4, 16, 32, 32, device=dev).bfloat16()
+    net(x).backward()  # (also marks the bias as summed by the channel-sum kernel: _gan_direct)
+    ref = {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}
+    arena = FlatArena(net.parameters(), with_grad=True)
+    arena.grad.fill_(123.0)  # stale values everywhere
+    arena.begin_direct()
+    assert net.w.grad is not None and net.b.grad is not None and net.unused.grad is None and net.gain.grad is None
+    with GF.direct_param_grads():
+        net(x).backward()
+    arena.gather_grads()
+    for k, p in net.named_parameters():
+        if k == "unused":
+            assert torch.count_nonzero(p.grad) == 0
+        else:
+            assert rel_err(p.grad, ref[k]) < 1e-5, (k, rel_err(p.grad, ref[k]))
+    assert all(p.grad.data_ptr() == arena.grad.data_ptr() + 4 * o for p, o in zip(arena.params, arena.offsets))
 
 
 def test_diff_augment_kernel(dev, golden, monkeypatch):
