@@ -83,6 +83,144 @@ __device__ __forceinline__ void frag_pixel(int g, int frow, int t8, int& img, in
     x = t8 ? (frow & 7) : frow;
 }
 
+// ---- output stages: lane holds channels co0 .. co0+3 (co0 = bn0 + wn*64 + 16*i + 4*fq) of its pixel of fragment f.
+// Absent stages cost nothing (wave-uniform branches, no out-of-range loads).  Shared by the two kernels below.
+template <int FC, int FP>
+__device__ __forceinline__ void halo_epilogue(const HaloArgs& p, f32x4 (&acc)[FC][FP], const int wm, const int wn, const int frow, const int fq,
+                                              const int n0, const int ty0, const int tx0, const int bn0) {
+    // ---- epilogue: lane holds channels co0 .. co0+3 (co0 = bn0 + wn*64 + 16*i + 4*fq) of its pixel of fragment f.
+    // Absent stages cost nothing (wave-uniform branches, no out-of-range loads).
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t raux = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.aux), 0, p.aux ? p.y_bytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.resid), 0, p.resid ? p.y_bytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rnz =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.noise), 0, p.noise ? p.y_bytes / (unsigned)p.Cout : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rosc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.out_scale), 0, p.out_scale ? (unsigned)(p.N * p.Cout) * 4u : 0u, 0x00020000);
+    const float gain = p.pool ? 0.25f * p.gain : p.gain;
+    const int Hy = p.pool ? p.Ho >> 1 : p.Ho, Wy = p.pool ? p.Wo >> 1 : p.Wo;
+    float4 bia[FC], nsc[FC];
+    int co0[FC];
+#pragma unroll
+    for (int i = 0; i < FC; ++i) {
+        co0[i] = bn0 + wn * 64 + i * 16 + fq * 4;
+        const bool cok = co0[i] < p.Cout;  // Cout % 8 == 0
+        bia[i] = (p.bias && cok) ? *reinterpret_cast<const float4*>(p.bias + co0[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        nsc[i] = (p.noise_scale && cok) ? *reinterpret_cast<const float4*>(p.noise_scale + co0[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    struct OutPixel {
+        int n;
+        unsigned obase;  // byte offset of the pixel's channel 0 in y / aux / resid, HALO_INV when this lane has none
+        float nz;
+    };
+    // The output stages are compiled three times -- plain (scale, bias, activation), with the input-gradient stages
+    // (mask / residual), with everything -- and picked once per workgroup: tested per fragment, the wave-uniform
+    // branches split the stage code into ~100 basic blocks with a wait in front of most.
+    auto epilogue = [&](auto modc, auto arc) {
+    constexpr bool MOD = decltype(modc)::value, AR = decltype(arc)::value;
+    // this lane's output pixel of fragment f (pooling: of the 2x2 window that fragments f, f+1 and lanes frow, frow^1 hold)
+    auto out_pixel = [&](const int f) {
+        int img, ly, lx;
+        frag_pixel(wm * FP + f, frow, p.t8, img, ly, lx);
+        OutPixel q;
+        q.n = n0 + img;
+        const int oy = ty0 + ly, ox = tx0 + lx;
+        const bool live = q.n < p.N && (!p.pool || (frow & 1) == 0);
+        const int opix = p.pool ? (q.n * Hy + (oy >> 1)) * Wy + (ox >> 1) : (q.n * Hy + oy) * Wy + ox;
+        q.obase = live ? (unsigned)opix * (unsigned)(p.Cout * 2) : HALO_INV;
+        q.nz = 0.f;
+        if (MOD && p.noise) q.nz = (float)__builtin_bit_cast(bf16, __builtin_amdgcn_raw_buffer_load_b16(rnz, live ? (unsigned)opix * 2u : HALO_INV, 0, 0));
+        return q;
+    };
+    // every output stage on the lane's 4 channels of fragment column i
+    auto finish = [&](const int i, const OutPixel& q, const f32x4 a) {
+        const unsigned off = (q.obase != HALO_INV && co0[i] < p.Cout) ? q.obase + co0[i] * 2 : HALO_INV;
+        float4 d4 = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (MOD && p.out_scale)
+            d4 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rosc, off != HALO_INV ? (unsigned)(q.n * p.Cout + co0[i]) * 4u : HALO_INV, 0, 0));
+        // (absent stages are wave-uniform branches: the plain layer is one fma per element, not a mul and two fmas)
+        float v[4];
+        if (MOD && p.out_scale) {
+            v[0] = fmaf(a[0] * gain, d4.x, bia[i].x);
+            v[1] = fmaf(a[1] * gain, d4.y, bia[i].y);
+            v[2] = fmaf(a[2] * gain, d4.z, bia[i].z);
+            v[3] = fmaf(a[3] * gain, d4.w, bia[i].w);
+        } else {
+            v[0] = fmaf(a[0], gain, bia[i].x);
+            v[1] = fmaf(a[1], gain, bia[i].y);
+            v[2] = fmaf(a[2], gain, bia[i].z);
+            v[3] = fmaf(a[3], gain, bia[i].w);
+        }
+        if (MOD && p.noise) {
+            v[0] = fmaf(q.nz, nsc[i].x, v[0]);
+            v[1] = fmaf(q.nz, nsc[i].y, v[1]);
+            v[2] = fmaf(q.nz, nsc[i].z, v[2]);
+            v[3] = fmaf(q.nz, nsc[i].w, v[3]);
+        }
+        if (p.slope != 1.f) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = lrelu_f(v[r], p.slope);
+        }
+        if (AR && p.aux) {
+            const bf16x4 a4 = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(raux, off, 0, 0));
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] *= lrelu_mask((float)a4[r], p.aux_slope);
+        }
+        if (AR && p.resid) {
+            const bf16x4 r4 = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(rres, off, 0, 0));
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += (float)r4[r];
+        }
+        bf16x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = (bf16)v[r];
+        return __builtin_bit_cast(v2u, o);
+    };
+    if (p.pool) {
+#pragma unroll
+        for (int f = 0; f < FP; f += 2) {
+            const OutPixel q = out_pixel(f);
+#pragma unroll
+            for (int i = 0; i < FC; ++i) {
+                f32x4 a;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {  // vertical neighbour in fragment f+1, horizontal one lane over (every lane executes the DPP add)
+                    a[r] = acc[i][f][r] + acc[i][f + 1][r];
+                    a[r] += quad_xor1(a[r]);
+                }
+                const v2u o = finish(i, q, a);
+                __builtin_amdgcn_raw_buffer_store_b64(o, ry, (q.obase != HALO_INV && co0[i] < p.Cout) ? q.obase + co0[i] * 2 : HALO_INV, 0, 0);
+            }
+        }
+    } else {
+        // Two fragments at a time: v_permlane16_swap trades the k-group-odd lanes' results of fragment f for the k-group-even
+        // lanes' results of fragment f+1, after which a lane holds 8 consecutive channels of ONE pixel: 16-byte stores, half as
+        // many of them (the store tail of a tile is issue-bound).
+#pragma unroll
+        for (int f = 0; f < FP; f += 2) {
+            const OutPixel qa = out_pixel(f), qb = out_pixel(f + 1);
+            const unsigned obase = (fq & 1) ? qb.obase : qa.obase;
+#pragma unroll
+            for (int i = 0; i < FC; ++i) {
+                v2u xa = finish(i, qa, acc[i][f]), xb = finish(i, qb, acc[i][f + 1]);
+#pragma unroll
+                for (int d = 0; d < 2; ++d) {
+                    const auto sw = __builtin_amdgcn_permlane16_swap(xa[d], xb[d], false, false);
+                    xa[d] = sw[0];
+                    xb[d] = sw[1];
+                }
+                const int cb8 = bn0 + wn * 64 + i * 16 + (fq >> 1) * 8;
+                const v4u o = {xa[0], xa[1], xb[0], xb[1]};
+                __builtin_amdgcn_raw_buffer_store_b128(o, ry, (obase != HALO_INV && cb8 < p.Cout) ? obase + cb8 * 2 : HALO_INV, 0, 0);
+            }
+        }
+    }
+    };
+    if (p.out_scale || p.noise) epilogue(std::true_type{}, std::true_type{});
+    else if (p.aux || p.resid) epilogue(std::false_type{}, std::true_type{});
+    else epilogue(std::false_type{}, std::false_type{});
+}
+
 template <int BN, int WAVES, bool UP2>
 __global__ void __launch_bounds__(WAVES * 64, 2) conv_wide_halo_k(const HaloArgs p) {
     constexpr int FC = 4, WN = BN / 64, WM = WAVES / WN;  // wave tile: FP*16 pixels x 64 channels
@@ -264,143 +402,214 @@ __global__ void __launch_bounds__(WAVES * 64, 2) conv_wide_halo_k(const HaloArgs
     }
 
     STAMP(9);
-    const int n0 = cur.n0, ty0 = cur.ty0, tx0 = cur.tx0, bn0 = cur.bn0;
-    // ---- epilogue: lane holds channels co0 .. co0+3 (co0 = bn0 + wn*64 + 16*i + 4*fq) of its pixel of fragment f.
-    // Absent stages cost nothing (wave-uniform branches, no out-of-range loads).
-    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t raux = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.aux), 0, p.aux ? p.y_bytes : 0u, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.resid), 0, p.resid ? p.y_bytes : 0u, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rnz =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.noise), 0, p.noise ? p.y_bytes / (unsigned)p.Cout : 0u, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rosc =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.out_scale), 0, p.out_scale ? (unsigned)(p.N * p.Cout) * 4u : 0u, 0x00020000);
-    const float gain = p.pool ? 0.25f * p.gain : p.gain;
-    const int Hy = p.pool ? p.Ho >> 1 : p.Ho, Wy = p.pool ? p.Wo >> 1 : p.Wo;
-    float4 bia[FC], nsc[FC];
-    int co0[FC];
-#pragma unroll
-    for (int i = 0; i < FC; ++i) {
-        co0[i] = bn0 + wn * 64 + i * 16 + fq * 4;
-        const bool cok = co0[i] < p.Cout;  // Cout % 8 == 0
-        bia[i] = (p.bias && cok) ? *reinterpret_cast<const float4*>(p.bias + co0[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
-        nsc[i] = (p.noise_scale && cok) ? *reinterpret_cast<const float4*>(p.noise_scale + co0[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+    halo_epilogue<FC, FP>(p, acc, wm, wn, frow, fq, cur.n0, cur.ty0, cur.tx0, cur.bn0);
 #ifdef GAN_HALO_STAMPS
+    STAMP(10);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    STAMP(11);
+    STAMP(13);
+    if (lane == 0 && blockIdx.y == 0 && blockIdx.x < 1024)
+        for (int k = 0; k < 16; ++k) halo_stamps[(blockIdx.x * WAVES + wave) * 16 + k] = st[k];
 #endif
-    struct OutPixel {
-        int n;
-        unsigned obase;  // byte offset of the pixel's channel 0 in y / aux / resid, HALO_INV when this lane has none
-        float nz;
-    };
-    // The output stages are compiled three times -- plain (scale, bias, activation), with the input-gradient stages
-    // (mask / residual), with everything -- and picked once per workgroup: tested per fragment, the wave-uniform
-    // branches split the stage code into ~100 basic blocks with a wait in front of most.
-    auto epilogue = [&](auto modc, auto arc) {
-    constexpr bool MOD = decltype(modc)::value, AR = decltype(arc)::value;
-    // this lane's output pixel of fragment f (pooling: of the 2x2 window that fragments f, f+1 and lanes frow, frow^1 hold)
-    auto out_pixel = [&](const int f) {
-        int img, ly, lx;
-        frag_pixel(wm * FP + f, frow, p.t8, img, ly, lx);
-        OutPixel q;
-        q.n = n0 + img;
-        const int oy = ty0 + ly, ox = tx0 + lx;
-        const bool live = q.n < p.N && (!p.pool || (frow & 1) == 0);
-        const int opix = p.pool ? (q.n * Hy + (oy >> 1)) * Wy + (ox >> 1) : (q.n * Hy + oy) * Wy + ox;
-        q.obase = live ? (unsigned)opix * (unsigned)(p.Cout * 2) : HALO_INV;
-        q.nz = 0.f;
-        if (MOD && p.noise) q.nz = (float)__builtin_bit_cast(bf16, __builtin_amdgcn_raw_buffer_load_b16(rnz, live ? (unsigned)opix * 2u : HALO_INV, 0, 0));
-        return q;
-    };
-    // every output stage on the lane's 4 channels of fragment column i
-    auto finish = [&](const int i, const OutPixel& q, const f32x4 a) {
-        const unsigned off = (q.obase != HALO_INV && co0[i] < p.Cout) ? q.obase + co0[i] * 2 : HALO_INV;
-        float4 d4 = make_float4(1.f, 1.f, 1.f, 1.f);
-        if (MOD && p.out_scale)
-            d4 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rosc, off != HALO_INV ? (unsigned)(q.n * p.Cout + co0[i]) * 4u : HALO_INV, 0, 0));
-        // (absent stages are wave-uniform branches: the plain layer is one fma per element, not a mul and two fmas)
-        float v[4];
-        if (MOD && p.out_scale) {
-            v[0] = fmaf(a[0] * gain, d4.x, bia[i].x);
-            v[1] = fmaf(a[1] * gain, d4.y, bia[i].y);
-            v[2] = fmaf(a[2] * gain, d4.z, bia[i].z);
-            v[3] = fmaf(a[3] * gain, d4.w, bia[i].w);
-        } else {
-            v[0] = fmaf(a[0], gain, bia[i].x);
-            v[1] = fmaf(a[1], gain, bia[i].y);
-            v[2] = fmaf(a[2], gain, bia[i].z);
-            v[3] = fmaf(a[3], gain, bia[i].w);
+}
+
+
+// ---- the 16-wide tiling (8 x 16 output pixels, 4 waves, two workgroups per CU) with an address-free K loop (round 3) ----
+// PMC on the kernel above (profiles/r03_pmc_summary.txt): 3.9 VALU instructions per MFMA, ~70 per K step -- fragment
+// addresses recomputed for every tap (the swizzle key depended on the halo row index, so on the tap), XORs for the second
+// K half and the second 8 bytes of every fragment, ring-stage arithmetic -- on a SIMD whose vector issue an MFMA holds
+// for 8 of its 16 cycles; and ~300 cycles per step of LDS-DMA issue in a phase of its own.  Here
+//   * the swizzle key of a halo row is a function of its COLUMN only ((hx >> 1) & 7: the pitch is even, so the 16 rows of
+//     a fragment still split into 8 even and 8 odd rows with distinct keys); a fragment's address is then
+//     base(lane, tap column DX) + a compile-time offset (tap row, fragment row, halo buffer): 3 x 4 base registers per
+//     lane for the halo and 4 for the weights, computed once per tile, every other term an instruction immediate;
+//   * the channel-block loop is unrolled by two so halo buffer and ring stage are compile-time;
+//   * LDS reads are volatile: with offsets it can see, the compiler fuses pairs of them into ds_read2st64_b64, which runs
+//     at half the LDS rate (32-bank mode);
+//   * the step's DMA pieces are issued between its MFMAs instead of in front of them.
+template <int OFF>
+__device__ __forceinline__ bf16x8 frag_read_imm(const __attribute__((address_space(3))) char* lds3, const unsigned a_lo, const unsigned a_hi) {
+    typedef const volatile __attribute__((address_space(3))) v2u* vp;
+    const v2u lo = *reinterpret_cast<vp>(lds3 + a_lo + OFF);
+    const v2u hi = *reinterpret_cast<vp>(lds3 + a_hi + OFF);
+    return __builtin_shufflevector(__builtin_bit_cast(bf16x4, lo), __builtin_bit_cast(bf16x4, hi), 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+template <int BN, bool UP2>
+__global__ void __launch_bounds__(256, 2) conv_wide_halo4_k(const HaloArgs p) {
+    constexpr int WAVES = 4, FC = 4, WN = BN / 64, WM = WAVES / WN, NFRAG = 8, FP = NFRAG / WM;
+    constexpr int PERW = BN / (8 * WAVES);            // weight pieces per wave and step
+    constexpr int W_BYTES = BN * 128;
+    constexpr int TW = 16, TH = 8;
+    constexpr int P = (UP2 ? TW / 2 : TW) + 2, HH = (UP2 ? TH / 2 : TH) + 2;  // halo pitch / rows in source pixels
+    constexpr int PERH = (P * HH + 8 * WAVES - 1) / (8 * WAVES);               // halo pieces per wave and channel block: 6 (2 upsampled)
+    constexpr int HB = PERH * WAVES * 1024;           // one halo buffer; the two-stage weight ring follows the two of them
+    constexpr int WRING = 2 * HB;
+    constexpr int NP = PERW + 1;  // DMA pieces per wave and step: one of the next halo, PERW of the next weights
+    static_assert(FP % 2 == 0, "tile");
+    extern __shared__ __attribute__((aligned(1024))) char lds_raw[];
+    char* const lds = lds_raw;
+    const __attribute__((address_space(3))) char* const lds3 = (const __attribute__((address_space(3))) char*)lds_raw;
+
+#ifdef GAN_HALO_STAMPS
+    unsigned long long st[16] = {};
+#endif
+    STAMP(0);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave % WN, wm = wave / WN;
+    const int frow = lane & 15, fq = lane >> 4, rsub = lane >> 3;
+
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wt), 0, p.w_bytes, 0x00020000);
+
+    // work item: a pixel tile x a BN-channel block of Cout (tiles of one channel block are consecutive workgroups)
+    const int item = blockIdx.x;
+    const int by = item / p.ntiles;
+    int bx = item - by * p.ntiles;
+    const int tx = bx % p.tiles_x;
+    bx /= p.tiles_x;
+    const int ty = bx % p.tiles_y, n0 = bx / p.tiles_y;
+    const int ty0 = ty * TH, tx0 = tx * TW, bn0 = by * BN;
+
+    // ---- DMA sources.  Piece q = j*WAVES + wave covers LDS rows 8q .. 8q+7, 8 lanes (16-byte chunks) per row; slot
+    // `lane & 7` of a row holds source chunk (lane & 7) ^ key(row): halo rows key = (column >> 1) & 7, weight rows
+    // key = (row >> 1) & 7 = (wave & 1) * 4 + rsub / 2.
+    unsigned hv[PERH], b_off[PERW];
+    {
+        const int sy0 = (UP2 ? ty0 >> 1 : ty0) - 1, sx0 = (UP2 ? tx0 >> 1 : tx0) - 1;
+        constexpr float inv_p = 1.0f / (float)P;
+#pragma unroll
+        for (int j = 0; j < PERH; ++j) {
+            const int hidx = (j * WAVES + wave) * 8 + rsub;            // < 256: the reciprocal multiply is exact after the +0.5
+            const int hy = (int)(((float)hidx + 0.5f) * inv_p), hx = hidx - hy * P;
+            const int sy = sy0 + hy, sx = sx0 + hx;
+            const bool ok = hy < HH && n0 < p.N && (unsigned)sy < (unsigned)p.H && (unsigned)sx < (unsigned)p.W;
+            const int csrc = (lane & 7) ^ ((hx >> 1) & 7);
+            hv[j] = ok ? (unsigned)(((n0 * p.H + sy) * p.W + sx) * p.Cin + csrc * 8) * 2u : HALO_INV;
         }
-        if (MOD && p.noise) {
-            v[0] = fmaf(q.nz, nsc[i].x, v[0]);
-            v[1] = fmaf(q.nz, nsc[i].y, v[1]);
-            v[2] = fmaf(q.nz, nsc[i].z, v[2]);
-            v[3] = fmaf(q.nz, nsc[i].w, v[3]);
+        const int csw = (lane & 7) ^ (((wave & 1) << 2) | (rsub >> 1));
+#pragma unroll
+        for (int j = 0; j < PERW; ++j) {
+            const int co = bn0 + (j * WAVES + wave) * 8 + rsub;
+            b_off[j] = co < p.Cout ? (unsigned)(co * p.Kpad + csw * 8) * 2u : HALO_INV;
         }
-        if (p.slope != 1.f) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = lrelu_f(v[r], p.slope);
-        }
-        if (AR && p.aux) {
-            const bf16x4 a4 = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(raux, off, 0, 0));
+        for (int j = 0; j < PERH; ++j) dma_piece(rx, lds + (j * WAVES + wave) * 1024, hv[j], 0);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] *= lrelu_mask((float)a4[r], p.aux_slope);
-        }
-        if (AR && p.resid) {
-            const bf16x4 r4 = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(rres, off, 0, 0));
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] += (float)r4[r];
-        }
-        bf16x4 o;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = (bf16)v[r];
-        return __builtin_bit_cast(v2u, o);
-    };
-    if (p.pool) {
-#pragma unroll
-        for (int f = 0; f < FP; f += 2) {
-            const OutPixel q = out_pixel(f);
-#pragma unroll
-            for (int i = 0; i < FC; ++i) {
-                f32x4 a;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {  // vertical neighbour in fragment f+1, horizontal one lane over (every lane executes the DPP add)
-                    a[r] = acc[i][f][r] + acc[i][f + 1][r];
-                    a[r] += quad_xor1(a[r]);
-                }
-                const v2u o = finish(i, q, a);
-                __builtin_amdgcn_raw_buffer_store_b64(o, ry, (q.obase != HALO_INV && co0[i] < p.Cout) ? q.obase + co0[i] * 2 : HALO_INV, 0, 0);
-            }
-        }
-    } else {
-        // Two fragments at a time: v_permlane16_swap trades the k-group-odd lanes' results of fragment f for the k-group-even
-        // lanes' results of fragment f+1, after which a lane holds 8 consecutive channels of ONE pixel: 16-byte stores, half as
-        // many of them (the store tail of a tile is issue-bound).
-#pragma unroll
-        for (int f = 0; f < FP; f += 2) {
-            const OutPixel qa = out_pixel(f), qb = out_pixel(f + 1);
-            const unsigned obase = (fq & 1) ? qb.obase : qa.obase;
-            if (f == 2) STAMP(12);
-#pragma unroll
-            for (int i = 0; i < FC; ++i) {
-                v2u xa = finish(i, qa, acc[i][f]), xb = finish(i, qb, acc[i][f + 1]);
-#pragma unroll
-                for (int d = 0; d < 2; ++d) {
-                    const auto sw = __builtin_amdgcn_permlane16_swap(xa[d], xb[d], false, false);
-                    xa[d] = sw[0];
-                    xb[d] = sw[1];
-                }
-                const int cb8 = bn0 + wn * 64 + i * 16 + (fq >> 1) * 8;
-                const v4u o = {xa[0], xa[1], xb[0], xb[1]};
-                __builtin_amdgcn_raw_buffer_store_b128(o, ry, (obase != HALO_INV && cb8 < p.Cout) ? obase + cb8 * 2 : HALO_INV, 0, 0);
-            }
-        }
+        for (int j = 0; j < PERW; ++j) dma_piece(rw, lds + WRING + (j * WAVES + wave) * 1024, b_off[j], 0);
     }
+
+    // ---- fragment base addresses: [0] first half, [1] second half of the K-half-0 chunk, [2], [3] the same for K half 1
+    const unsigned c8 = (unsigned)(fq & 1) << 3;
+    unsigned hx4[3][4], wa4[4];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+        const int sx = UP2 ? ((frow + dx - 1) >> 1) + 1 : frow + dx;          // halo column of this lane's pixel at tap column dx
+        const int row0 = (UP2 ? wm * (FP / 2) : wm * FP) * P + sx;             // + the wave's first tile row (source rows when upsampled)
+        const unsigned b = (unsigned)(row0 << 7) + (unsigned)(((fq ^ (sx >> 1)) & 7) << 4) + c8;
+        hx4[dx][0] = b; hx4[dx][1] = b ^ 8u; hx4[dx][2] = b ^ 64u; hx4[dx][3] = b ^ 72u;
+    }
+    {
+        const unsigned b = (unsigned)((wn * 64 + frow) << 7) + (unsigned)((fq ^ (frow >> 1)) << 4) + c8;
+        wa4[0] = b; wa4[1] = b ^ 8u; wa4[2] = b ^ 64u; wa4[3] = b ^ 72u;
+    }
+
+    f32x4 acc[FC][FP];
+#pragma unroll
+    for (int i = 0; i < FC; ++i)
+#pragma unroll
+        for (int f = 0; f < FP; ++f) acc[i][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+    STAMP(1);
+
+    // One K step = one tap of one channel block; TAP and the parity CB of the channel block are constant expressions.
+    //  - W(t) and (tap 0) the block's halo have landed once nothing this wave issued is outstanding; the barrier says so
+    //    for every wave, and that every wave is done with step t-1's ring stage;
+    //  - all 2 * (FC + FP) fragment reads of the step, then the MFMAs of the first K half with, between them, one piece of
+    //    the next channel block's halo (taps 1 .. PERH) and the weights of step t+1; then the second K half.
+    auto step = [&](auto tapc, auto cbc, const int cbi, const bool last_cb) {
+        constexpr int TAP = decltype(tapc)::value, CB = decltype(cbc)::value;
+        constexpr int DY = TAP / 3, DX = TAP % 3;
+        constexpr int HOFF = CB * HB;
+        constexpr int WOFF = WRING + ((CB + TAP) & 1) * W_BYTES;
+        constexpr int T2 = (TAP + 1) % 9, CB2 = CB + (TAP == 8 ? 1 : 0);  // the step whose weights are issued here
+        constexpr int WNEXT = WRING + ((CB2 + T2) & 1) * W_BYTES;
+        const bool stamped = TAP == 4 && cbi == 1;
+        (void)stamped;
+        if (stamped) STAMP(3);
+        wait_vm<0>();
+        if (stamped) STAMP(4);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (stamped) STAMP(5);
+        const int cb2 = cbi + (TAP == 8 ? 1 : 0);
+        const bool w_next = cb2 < p.ncb, h_next = TAP >= 1 && TAP <= PERH && !last_cb;
+        auto issue = [&](const int k) {  // piece k of this step's DMA: 0 = halo, 1 .. PERW = weights
+            if (k == 0) {
+                if constexpr (TAP >= 1 && TAP <= PERH) {
+                    if (h_next) dma_piece(rx, lds + (CB ^ 1) * HB + ((TAP - 1) * WAVES + wave) * 1024, hv[TAP - 1], (cbi + 1) * 128);
+                }
+            } else if (w_next) {
+                dma_piece(rw, lds + WNEXT + ((k - 1) * WAVES + wave) * 1024, b_off[k - 1], (T2 * p.Cin + cb2 * 64) * 2);
+            }
+        };
+        // first K half's fragments, then the step's DMA pieces (issued while those reads are in flight), then per half
+        // 16 MFMAs; the second half's reads go out under the first half's MFMAs
+        auto read_half = [&](auto hc, bf16x8 (&wf)[FC], bf16x8 (&xf)[FP]) {
+            constexpr int H = decltype(hc)::value;
+#pragma unroll
+            for (int i = 0; i < FC; ++i) {
+                wf[i] = i == 0 ? frag_read_imm<WOFF>(lds3, wa4[2 * H], wa4[2 * H + 1])
+                      : i == 1 ? frag_read_imm<WOFF + 2048>(lds3, wa4[2 * H], wa4[2 * H + 1])
+                      : i == 2 ? frag_read_imm<WOFF + 4096>(lds3, wa4[2 * H], wa4[2 * H + 1])
+                               : frag_read_imm<WOFF + 6144>(lds3, wa4[2 * H], wa4[2 * H + 1]);
+            }
+#pragma unroll
+            for (int f = 0; f < FP; ++f) {
+                // row of fragment f at this tap: (f + DY) rows below the wave's first; source rows when upsampled
+                auto rd = [&](auto fc) {
+                    constexpr int F = decltype(fc)::value;
+                    constexpr int ROW = UP2 ? ((F + DY - 1) >> 1) + 1 : F + DY;
+                    return frag_read_imm<HOFF + ROW * P * 128>(lds3, hx4[DX][2 * H], hx4[DX][2 * H + 1]);
+                };
+                xf[f] = f == 0 ? rd(std::integral_constant<int, 0>{}) : f == 1 ? rd(std::integral_constant<int, 1>{})
+                      : f == 2 ? rd(std::integral_constant<int, 2>{}) : rd(std::integral_constant<int, 3>{});
+            }
+        };
+        bf16x8 wf0[FC], xf0[FP], wf1[FC], xf1[FP];
+        read_half(std::integral_constant<int, 0>{}, wf0, xf0);
+#pragma unroll
+        for (int k = 0; k < NP; ++k) issue(k);
+        if (stamped) STAMP(6);
+        read_half(std::integral_constant<int, 1>{}, wf1, xf1);
+#pragma unroll
+        for (int i = 0; i < FC; ++i)
+#pragma unroll
+            for (int f = 0; f < FP; ++f) acc[i][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf0[i], xf0[f], acc[i][f], 0, 0, 0);
+        if (stamped) STAMP(7);
+#pragma unroll
+        for (int i = 0; i < FC; ++i)
+#pragma unroll
+            for (int f = 0; f < FP; ++f) acc[i][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf1[i], xf1[f], acc[i][f], 0, 0, 0);
+        if (stamped) STAMP(8);
     };
-    if (p.out_scale || p.noise) epilogue(std::true_type{}, std::true_type{});
-    else if (p.aux || p.resid) epilogue(std::false_type{}, std::true_type{});
-    else epilogue(std::false_type{}, std::false_type{});
+    auto block = [&](auto cbc, const int cbi, const bool last_cb) {
+        step(std::integral_constant<int, 0>{}, cbc, cbi, last_cb);
+        step(std::integral_constant<int, 1>{}, cbc, cbi, last_cb);
+        step(std::integral_constant<int, 2>{}, cbc, cbi, last_cb);
+        step(std::integral_constant<int, 3>{}, cbc, cbi, last_cb);
+        step(std::integral_constant<int, 4>{}, cbc, cbi, last_cb);
+        step(std::integral_constant<int, 5>{}, cbc, cbi, last_cb);
+        step(std::integral_constant<int, 6>{}, cbc, cbi, last_cb);
+        step(std::integral_constant<int, 7>{}, cbc, cbi, last_cb);
+        step(std::integral_constant<int, 8>{}, cbc, cbi, last_cb);
+    };
+    for (int cbi = 0; cbi < p.ncb; cbi += 2) {
+        block(std::integral_constant<int, 0>{}, cbi, cbi + 1 == p.ncb);
+        if (cbi + 1 == p.ncb) break;
+        block(std::integral_constant<int, 1>{}, cbi + 1, cbi + 2 == p.ncb);
+    }
+
+    STAMP(9);
+    halo_epilogue<FC, FP>(p, acc, wm, wn, frow, fq, n0, ty0, tx0, bn0);
 #ifdef GAN_HALO_STAMPS
     STAMP(10);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -480,7 +689,16 @@ int gan_conv2d_fwd_wide_halo(const void* x, const void* wt, void* y, const float
     const int64_t items = tiles * gn;
     const size_t lds = (size_t)2 * a.perh * waves * 1024 + (size_t)(waves == 8 ? 3 : 2) * BN * 128;
     const dim3 grid((unsigned)items);
-    if (waves == 4 && BN == 128 && up2)
+    static const bool halo4 = !(getenv("GAN_AMD_HALO4") && atoi(getenv("GAN_AMD_HALO4")) == 0);  // 0: the round-2 kernel (A/B runs)
+    if (waves == 4 && halo4 && BN == 128 && up2)
+        hipLaunchKernelGGL((conv_wide_halo4_k<128, true>), grid, dim3(256), lds, st, a);
+    else if (waves == 4 && halo4 && BN == 128)
+        hipLaunchKernelGGL((conv_wide_halo4_k<128, false>), grid, dim3(256), lds, st, a);
+    else if (waves == 4 && halo4 && up2)
+        hipLaunchKernelGGL((conv_wide_halo4_k<64, true>), grid, dim3(256), lds, st, a);
+    else if (waves == 4 && halo4)
+        hipLaunchKernelGGL((conv_wide_halo4_k<64, false>), grid, dim3(256), lds, st, a);
+    else if (waves == 4 && BN == 128 && up2)
         hipLaunchKernelGGL((conv_wide_halo_k<128, 4, true>), grid, dim3(256), lds, st, a);
     else if (waves == 4 && BN == 128)
         hipLaunchKernelGGL((conv_wide_halo_k<128, 4, false>), grid, dim3(256), lds, st, a);
