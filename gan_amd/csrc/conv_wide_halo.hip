@@ -454,7 +454,8 @@ __global__ void __launch_bounds__(256, 2) conv_wide_halo4_k(const HaloArgs p) {
     unsigned long long st[16] = {};
 #endif
     STAMP(0);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: every DMA destination (M0) is then scalar arithmetic
     const int wn = wave % WN, wm = wave / WN;
     const int frow = lane & 15, fq = lane >> 4, rsub = lane >> 3;
 

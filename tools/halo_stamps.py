@@ -22,10 +22,9 @@ lib.gan_debug_halo_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
 assert lib.gan_debug_halo_stamps(buf.ctypes.data, buf.size) == 0
 st = buf.reshape(nb, waves, 16).astype(np.int64)
 names = {(0, 1): "prologue (decode + first DMA issue)", (1, 9): "K loop", (9, 10): "epilogue", (0, 10): "kernel (wave lifetime)",
-         (9, 11): "epilogue: bias loads landed", (11, 12): "epilogue: first fragment pair", (12, 10): "epilogue: second pair, stores issued",
          (10, 13): "epilogue: stores drained",
-         (3, 4): "step: vmcnt wait", (4, 5): "step: barrier", (5, 6): "step: DMA issue", (6, 7): "step: addresses + reads + 16 MFMA (h=0)",
-         (7, 8): "step: reads + 16 MFMA (h=1)", (3, 8): "step total"}
+         (3, 4): "step: vmcnt wait", (4, 5): "step: barrier", (5, 6): "step: first-half reads + DMA issue", (6, 7): "step: second-half reads + 16 MFMA (h=0)",
+         (7, 8): "step: 16 MFMA (h=1)", (3, 8): "step total"}
 for (a, b), name in names.items():
     d = st[:, :, b] - st[:, :, a]
     print(f"{name:45s} median {np.median(d):9.0f}  p10 {np.percentile(d, 10):9.0f}  p90 {np.percentile(d, 90):9.0f}")
