@@ -5,10 +5,10 @@
 //
 // Same idea as the thin kernel -- stage a block of pixels ONCE in LDS and form every tap from that
 // image -- organised for 128..512 channels on 4x4..64x64 maps:
-//   * a workgroup (3 waves) owns a 64 x 64 (co x ci) channel tile and a contiguous range of 128-pixel
+//   * a workgroup owns a 64 x 64 (co x ci) channel tile and a contiguous range of 128-pixel
 //     spatial tiles: TH x 32 rows of one image, half / whole 16 x 16 images, 2 images of 8 x 8, 8 of 4 x 4;
-//   * wave w owns kernel row dy = w: 3 taps x 16 fragment accumulators (192 registers) that live
-//     across all tiles of the workgroup (1x1 convolutions: the waves split the K steps instead);
+//   * consumer wave w (four, one per SIMD) owns input channels 16w .. 16w+15 of the tile: taps x 4 fragment
+//     accumulators (144 registers for 3x3) that live across all tiles of the workgroup;
 //   * k = 32 consecutive tile-linear pixels per MFMA; both operands are pixel-major, stored as
 //     [16-channel group][pixel][16 ch] and read with ds_read_b64_tr_b16 (per-lane halo offsets);
 //   * split-K over pixel tiles: every workgroup writes its partial tile with plain stores into slice
@@ -60,16 +60,17 @@ __device__ __forceinline__ bf16x8 tr_frag2(const char* plo, const char* phi) {
 #ifndef GAN_TW_LOADERS
 #define GAN_TW_LOADERS 4
 #endif
-constexpr int TW_LOADERS = GAN_TW_LOADERS;  // producer waves (waves 3..6); waves 0-2 are MFMA consumers
-constexpr int TW_BIAS_WAVE = 3 + TW_LOADERS;  // one more wave: sum_pixels gy = gy^T x ones on the MFMA (the bias gradient)
-constexpr int TW_THREADS = 192 + 64 * TW_LOADERS + 64;
+constexpr int TW_CONSUMERS = 4;               // MFMA consumer waves 0..3, one per SIMD: wave w owns input channels 16w .. 16w+15 of the tile
+constexpr int TW_LOADERS = GAN_TW_LOADERS;    // producer waves (waves 4..7)
+constexpr int TW_BIAS_WAVE = TW_CONSUMERS + TW_LOADERS;  // one more wave: sum_pixels gy = gy^T x ones on the MFMA (the bias gradient)
+constexpr int TW_THREADS = 64 * TW_CONSUMERS + 64 * TW_LOADERS + 64;
 
 
 // Tile geometry is a template parameter: the producers turn a chunk index into (image, row, column) with
 // divisions by HALO and HWD for every 16-byte load, which as run-time divisions made them VALU-bound
 // (PMC: consumers waited 67 % of their cycles on the stage barrier).
 template <int KS, int TWL, int THL, int NBL, bool MOD, bool BIAS>
-__global__ void __launch_bounds__(TW_THREADS) conv_wgrad_tiled_k(const TWArgs p) {
+__global__ void __launch_bounds__(BIAS ? TW_THREADS : TW_THREADS - 64) conv_wgrad_tiled_k(const TWArgs p) {
     extern __shared__ __attribute__((aligned(256))) char tw_lds[];
     constexpr int NT = KS;  // taps (dx) per consumer wave
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -83,8 +84,6 @@ __global__ void __launch_bounds__(TW_THREADS) conv_wgrad_tiled_k(const TWArgs p)
     const int t0 = (int)((int64_t)p.ntiles * s / p.S), t1 = (int)((int64_t)p.ntiles * (s + 1) / p.S);
     constexpr int thw_log2 = THL + TWL;
     const int tiles_per_img = p.tiles_x * p.tiles_y;
-
-    f32x4 acc[NT][4][4];
 
     if (BIAS && wave == TW_BIAS_WAVE) {  // (a template flag: with the branch compiled in, the consumers spill 12-36 bytes more and lose 12 %)
         // ================= the bias gradient: the gy planes of every stage against a fragment of ones ==============
@@ -121,7 +120,7 @@ __global__ void __launch_bounds__(TW_THREADS) conv_wgrad_tiled_k(const TWArgs p)
                     if (co < p.Cout) dst[co] = accb[o][r];
                 }
         }
-    } else if (wave >= 3) {
+    } else if (wave >= TW_CONSUMERS) {
         // ================= producers: tile t -> LDS stage (t - t0) & 1, TW_U loads in flight per lane ====
         typedef unsigned v4u __attribute__((ext_vector_type(4)));
         constexpr unsigned INV = 0x80000000u;  // past num_records (tensors < 2^31 bytes): the load returns zeros
@@ -129,7 +128,7 @@ __global__ void __launch_bounds__(TW_THREADS) conv_wgrad_tiled_k(const TWArgs p)
         const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.gy), 0, p.gy_bytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t rs =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in_scale), 0, MOD ? (unsigned)(p.N * p.Cin) * 4u : 0u, 0x00020000);
-        const int ltid = tid - 192;
+        const int ltid = tid - 64 * TW_CONSUMERS;
         constexpr int PL = 64 * TW_LOADERS;
         constexpr int nxc = ((NPX + 7) >> 3) * 64;  // x chunks (8 pixels x 8 channel chunks per 64)
         // Branch-free, division-free staging.  Slot `sl` of this lane always maps to the same (image b, row,
@@ -174,9 +173,7 @@ __global__ void __launch_bounds__(TW_THREADS) conv_wgrad_tiled_k(const TWArgs p)
             packed[sl] = yy | (xx << 8) | (bb << 16) | (okc << 25);
             dsto[sl] = d;
         }
-        for (int t = t0; t < t1; ++t) {
-            char* const xl = tw_lds + ((t - t0) & 1) * BUF;
-            int n0, oy0, ox0;
+        auto origin = [&](const int t, int& n0, int& oy0, int& ox0) {
             if (NB == 1) {
                 n0 = t / tiles_per_img;
                 const int rem = t - n0 * tiles_per_img;
@@ -187,6 +184,50 @@ __global__ void __launch_bounds__(TW_THREADS) conv_wgrad_tiled_k(const TWArgs p)
                 n0 = t * NB;
                 oy0 = ox0 = 0;
             }
+        };
+        if constexpr (!MOD) {
+            // Round 3: the loads of tile t+1 are issued right after tile t's chunks have gone to LDS, BEFORE the stage
+            // barrier, and stay in flight in registers while the producers wait for the consumers: the memory latency
+            // of a tile no longer sits between two barriers (a tile took ~5700 cycles for 2300 of MFMA work).
+            v4u v[NSLOT];
+            auto issue = [&](const int t) {
+                int n0, oy0, ox0;
+                origin(t, n0, oy0, ox0);
+                const int bx = ((n0 * p.H + (oy0 >> shx)) * p.W + (ox0 >> shx)) * p.Cin * 2;
+                const int bg = ((n0 * Hg + (oy0 >> shg)) * Wg + (ox0 >> shg)) * p.Cout * 2;
+#pragma unroll
+                for (int k = 0; k < NSLOT; ++k) {
+                    const bool isx = k < NSX;
+                    int pk = packed[k];
+                    asm volatile("" : "+v"(pk));  // keeps the decode below out of the tile loop's preheader (registers)
+                    const int nn = n0 + ((pk >> 16) & 0xff);
+                    const int y = (isx ? oy0 - p.py : oy0) + (pk & 0xff);
+                    const int xq = (isx ? ox0 - p.px : ox0) + ((pk >> 8) & 0xff);
+                    const bool ok = ((pk >> 25) & 1) && nn < p.N && (unsigned)y < (unsigned)(isx ? p.Hl : p.Ho) &&
+                                    (unsigned)xq < (unsigned)(isx ? p.Wl : p.Wo);
+                    const unsigned off = ok ? (unsigned)((isx ? bx : bg) + rel[k]) : INV;
+                    v[k] = __builtin_amdgcn_raw_buffer_load_b128(isx ? rx : rg, off, 0, 0);
+                }
+            };
+            if (t0 < t1) issue(t0);
+            for (int t = t0; t < t1; ++t) {
+                char* const xl = tw_lds + ((t - t0) & 1) * BUF;
+                const int dump = 2 * BUF + ltid * 16 - ((t - t0) & 1) * BUF;
+#pragma unroll
+                for (int k = 0; k < NSLOT; ++k) {
+                    uint4 u = make_uint4(v[k][0], v[k][1], v[k][2], v[k][3]);
+                    if (k < NSX && p.fu.x_slope != 1.f) u = lrelu_chunk(u, p.fu.x_slope, bf16());
+                    const int d = dsto[k];
+                    *reinterpret_cast<uint4*>(xl + (d >= 0 ? d : dump)) = u;
+                }
+                if (t + 1 < t1) issue(t + 1);
+                __syncthreads();  // stage ready; consumers have left the stage this overwrites two tiles later
+            }
+        } else {
+        for (int t = t0; t < t1; ++t) {
+            char* const xl = tw_lds + ((t - t0) & 1) * BUF;
+            int n0, oy0, ox0;
+            origin(t, n0, oy0, ox0);
             // wave-uniform bases of the tile (bytes)
             const int bx = ((n0 * p.H + (oy0 >> shx)) * p.W + (ox0 >> shx)) * p.Cin * 2;
             const int bg = ((n0 * Hg + (oy0 >> shg)) * Wg + (ox0 >> shg)) * p.Cout * 2;
@@ -238,78 +279,56 @@ __global__ void __launch_bounds__(TW_THREADS) conv_wgrad_tiled_k(const TWArgs p)
             }
             __syncthreads();  // stage ready; consumers have left the stage this overwrites two tiles later
         }
+        }
     } else {
-        // ================= consumers: wave = kernel row dy (1x1: the waves split the K steps) ============
+        // ================= consumers: wave = 16-channel group of the tile's input channels, every tap ============
+        // (round 3.  Rounds 1-2 gave each of THREE waves a kernel row: a CU's fourth SIMD issued no MFMA, and 1x1 layers,
+        // whose waves split the K steps instead, folded three partial tiles through LDS at the end.  With the ci split a
+        // tile is 144 MFMAs on each of four SIMDs instead of 192 on three, the accumulators are 144 registers (were
+        // 192), and every wave stores its own columns of every tap.)
+        f32x4 acc[NT * NT][4];
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
+        for (int j = 0; j < NT * NT; ++j)
 #pragma unroll
-            for (int o = 0; o < 4; ++o)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) acc[j][o][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int o = 0; o < 4; ++o) acc[j][o] = f32x4{0.f, 0.f, 0.f, 0.f};
         for (int t = t0; t < t1; ++t) {
             __syncthreads();  // tile t is in its stage
-            const char* const xl = tw_lds + ((t - t0) & 1) * BUF;
-            const char* const gl = xl + 4 * PLX;
+            const char* const xl = tw_lds + ((t - t0) & 1) * BUF + wave * PLX;
+            const char* const gl = tw_lds + ((t - t0) & 1) * BUF + 4 * PLX;
 #pragma unroll 1
             for (int ks = 0; ks < 4; ++ks) {
-                if (KS == 1 && (ks % 3) != wave) continue;
-                if (KS == 2 && wave == 2) continue;  // two kernel rows: the third consumer wave only keeps the barriers
                 const int Plo = ks * 32 + 4 * g + q, Phi = Plo + 16;
                 bf16x8 a[4];
 #pragma unroll
                 for (int o = 0; o < 4; ++o) a[o] = tr_frag2(gl + o * PLG + Plo * 32 + pp * 8, gl + o * PLG + Phi * 32 + pp * 8);
-                const int dy = KS == 1 ? 0 : wave;
-                const int hlo = (Plo >> thw_log2) * HALO + (((Plo >> TWL) & (TH - 1)) + dy) * HWD + (Plo & (TW - 1));
-                const int hhi = (Phi >> thw_log2) * HALO + (((Phi >> TWL) & (TH - 1)) + dy) * HWD + (Phi & (TW - 1));
+                const int hlo = (Plo >> thw_log2) * HALO + ((Plo >> TWL) & (TH - 1)) * HWD + (Plo & (TW - 1));
+                const int hhi = (Phi >> thw_log2) * HALO + ((Phi >> TWL) & (TH - 1)) * HWD + (Phi & (TW - 1));
                 const char* const blo = xl + hlo * 32 + pp * 8;
                 const char* const bhi = xl + hhi * 32 + pp * 8;
 #pragma unroll
-                for (int dx = 0; dx < NT; ++dx) {
+                for (int dy = 0; dy < NT; ++dy)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const bf16x8 b = tr_frag2(blo + i * PLX + dx * 32, bhi + i * PLX + dx * 32);
+                    for (int dx = 0; dx < NT; ++dx) {
+                        const bf16x8 b = tr_frag2(blo + (dy * HWD + dx) * 32, bhi + (dy * HWD + dx) * 32);
 #pragma unroll
                         for (int o = 0; o < 4; ++o)
-                            acc[dx][o][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[o], b, acc[dx][o][i], 0, 0, 0);
+                            acc[dy * NT + dx][o] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[o], b, acc[dy * NT + dx][o], 0, 0, 0);
                     }
-                }
             }
         }
-        // ---- partial tile -> workspace slice s, final layout [tap][Cout][Cin] (3x3: one tap row per wave)
-        if (KS != 1 && wave < KS) {
-            float* __restrict__ slice = p.ws + (int64_t)s * p.Lp;
+        // ---- partial tile -> workspace slice s, final layout [tap][Cout][Cin]
+        float* __restrict__ slice = p.ws + (int64_t)s * p.Lp;
+        const int ci = ci0 + wave * 16 + li;
 #pragma unroll
-            for (int dx = 0; dx < NT; ++dx) {
-                float* __restrict__ dst = slice + (int64_t)(wave * KS + dx) * p.Cout * p.Cin;
-#pragma unroll
-                for (int o = 0; o < 4; ++o)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int co = co0 + o * 16 + g * 4 + r, ci = ci0 + i * 16 + li;
-                            if (co < p.Cout && ci < p.Cin) dst[(int64_t)co * p.Cin + ci] = acc[dx][o][i][r];
-                        }
-            }
-        }
-    }
-    if (KS == 1) {
-        // three consumer waves hold partial sums of the same tap: fold them through LDS (all loads landed)
-        __syncthreads();
-        float* red = reinterpret_cast<float*>(tw_lds);
-        if (wave < 3) {
+        for (int tap = 0; tap < NT * NT; ++tap) {
+            float* __restrict__ dst = slice + (int64_t)tap * p.Cout * p.Cin;
 #pragma unroll
             for (int o = 0; o < 4; ++o)
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) red[wave * 4096 + (o * 16 + g * 4 + r) * 64 + i * 16 + li] = acc[0][o][i][r];
-        }
-        __syncthreads();
-        float* __restrict__ slice = p.ws + (int64_t)s * p.Lp;
-        for (int e = tid; e < 4096; e += (int)blockDim.x) {
-            const int co = co0 + (e >> 6), ci = ci0 + (e & 63);
-            if (co < p.Cout && ci < p.Cin) slice[(int64_t)co * p.Cin + ci] = red[e] + red[4096 + e] + red[8192 + e];
+                for (int r = 0; r < 4; ++r) {
+                    const int co = co0 + o * 16 + g * 4 + r;
+                    if (co < p.Cout && ci < p.Cin) dst[(int64_t)co * p.Cin + ci] = acc[tap][o][r];
+                }
         }
     }
 }
@@ -405,7 +424,6 @@ TiledPlan plan_tiled(int N, int Ho, int Wo, int Cin, int Cout, int ks) {
     pl.S = S;
     const int NPX = NB * (TW + ks - 1) * (TH + ks - 1);
     pl.lds = 2 * (4 * NPX * 32 + 4 * 128 * 32) + 64 * TW_LOADERS * 16;  // two stages + the producers' dump slots
-    if (ks == 1 && pl.lds < 3 * 4096 * 4) pl.lds = 3 * 4096 * 4;
     pl.ok = true;
     return pl;
 }

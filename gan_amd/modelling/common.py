@@ -126,13 +126,17 @@ class _StridedConv2d(nn.Conv2d):
     def forward(self, x: Tensor) -> Tensor:
         if self.stride == (1, 1):
             return Conv2d.forward(self, x)
+        return self._forward_with(x, self.weight, self.kernel_size[0])
+
+    def _forward_with(self, x: Tensor, weight: Tensor, k: int) -> Tensor:
+        """The stride-2 layer with `weight` (Cout, Cin, k, k) in place of the parameter (a zero-extended odd kernel)."""
         if self.stride != (2, 2):
             raise GF._lib.GanAmdError("gan_amd strided Conv2d supports stride 1 or 2")
         x = to_act(x)
-        k, p = self.kernel_size[0], self.padding[0]
-        if k % 2 == 0 and k == self.kernel_size[1] and p == self.padding[1] and (x.shape[2] + 2 * p) % 2 == 0 and (x.shape[3] + 2 * p) % 2 == 0:
+        p = self.padding[0]
+        if k % 2 == 0 and weight.shape[2] == weight.shape[3] and p == self.padding[1] and (x.shape[2] + 2 * p) % 2 == 0 and (x.shape[3] + 2 * p) % 2 == 0:
             xs = GF.SpaceToDepthFn.apply(x, p)
-            return GF.conv_bias_act(xs, _fold_weight(self.weight), self.bias, 0)
+            return GF.conv_bias_act(xs, _fold_weight(weight), self.bias, 0)
         y = GF.Conv2dFn.apply(x, self.weight, self.padding[0], self.padding[1])
         y = GF.upfirdn2d(y, torch.ones(1, 1, device=x.device), 1, 2, 0, 0, 0, 0)
         return GF.affine_act(y, b=self.bias) if self.bias is not None else y
@@ -145,23 +149,27 @@ class _ConvTranspose2d(nn.ConvTranspose2d):
     correlation with the transposed, flipped weights."""
 
     def forward(self, x: Tensor) -> Tensor:
-        k, p, op, st = self.kernel_size[0], self.padding[0], self.output_padding[0], self.stride[0]
+        return self._forward_with(x, self.weight, self.kernel_size[0], self.output_padding[0])
+
+    def _forward_with(self, x: Tensor, weight: Tensor, k: int, op: int) -> Tensor:
+        """The layer with `weight` (Cin, Cout, k, k) and output_padding `op` in place of its own (a zero-extended odd kernel)."""
+        p, st = self.padding[0], self.stride[0]
         if st not in (1, 2) or self.groups != 1 or self.dilation != (1, 1):
             raise GF._lib.GanAmdError("gan_amd ConvTranspose2d supports stride 1 or 2, groups 1, dilation 1")
         x = to_act(x)
         full = k - 1 - p
-        if st == 2 and k % 2 == 0 and op == 0 and k == self.kernel_size[1]:
+        if st == 2 and k % 2 == 0 and op == 0 and weight.shape[2] == weight.shape[3]:
             # the adjoint of the strided convolution above: input gradient of the folded valid convolution (a stride-1
             # correlation with the flipped, transposed folded weights), then depth-to-space with the crop
             n, _, h, w = x.shape
             m = k // 2
-            y4 = GF.Conv2dDgradFn.apply(x, _fold_weight(self.weight), 0, 0)  # (N, 4 Cout, h + m - 1, w + m - 1)
+            y4 = GF.Conv2dDgradFn.apply(x, _fold_weight(weight), 0, 0)  # (N, 4 Cout, h + m - 1, w + m - 1)
             y = GF.DepthToSpaceFn.apply(y4, p, 2 * (h + m - 1) - 2 * p, 2 * (w + m - 1) - 2 * p)
             return GF.affine_act(y, b=self.bias) if self.bias is not None else y
         if st == 2:
             x = GF.upfirdn2d(x, torch.ones(1, 1, device=x.device), 2, 1, full, full - 1 + op, full, full - 1 + op)
             full = 0
-        w = self.weight.flip(2, 3).transpose(0, 1)
+        w = weight.flip(2, 3).transpose(0, 1)
         y = GF.Conv2dFn.apply(x, w, full, full)
         return GF.affine_act(y, b=self.bias) if self.bias is not None else y
 

@@ -1,9 +1,10 @@
 """DCGAN generator / discriminator (BASELINE config 5: WGAN-GP, n_disc=5).
 
 Reference: modelling/dcgan.py:16-72 -- same constructor signatures, child layout and state_dict keys.
-Convolutions run on the MFMA implicit-GEMM kernel (stride-2 convs as stride-1 correlation + subsample,
-transposed convs as zero insertion + correlation), so the gradient-penalty double backward through the
-discriminator stays on the HIP kernels.  BatchNorm (generator only, never double-differentiated in the
+Convolutions run on the MFMA kernels: the 4x4 stride-2 convolutions as space-to-depth (gan_space_to_depth) + a stride-1
+2x2 valid convolution over the folded weight, the stride-2 transposed convolutions as that map's adjoint (input gradient
+of the folded convolution + depth-to-space) -- no wasted products -- so the gradient-penalty double backward through
+the discriminator stays on the HIP kernels.  BatchNorm (generator only, never double-differentiated in the
 step) and ReLU/Tanh stay on stock PyTorch-ROCm, as SURVEY.md section 2 row 6 scopes them.
 """
 from __future__ import annotations

@@ -17,7 +17,9 @@ import torch
 from torch import Tensor, nn
 
 from .. import functional as GF
-from .common import AvgPool2d, Conv2d, Upsample, to_act
+import torch.nn.functional as F
+
+from .common import AvgPool2d, Conv2d, Upsample, _ConvTranspose2d, _StridedConv2d, to_act
 
 # The reference's autograd.Function: `UpFIRDn2d.apply(...)` with the same 8 positionals.  Every
 # order of gradient re-enters the same HIP kernel with flipped taps and up/down swapped.
@@ -54,32 +56,29 @@ class Blur(nn.Module):
         return row.view(1, -1) * row.view(-1, 1)
 
 
-class _ZeroStuffConvTranspose2d(nn.ConvTranspose2d):
-    """ConvTranspose2d(stride 2) = zero-insert x2 (upfirdn2d with a unit tap) + stride-1 correlation
-    with the transposed, flipped weights."""
+class _ZeroStuffConvTranspose2d(_ConvTranspose2d):
+    """ConvTranspose2d(k, stride 2, (k-1)//2, output_padding k % 2) of up_conv_blur (nvidia_ops.py:93-101).  Odd k: the
+    kernel gets a zero row and column (k -> k + 1, output_padding 1 -> 0: the same map, the same output size) and runs as
+    the adjoint of a space-to-depth folded convolution (common._ConvTranspose2d) -- no zero-stuffed 4x tensor, 1.8x the
+    useful products instead of 4x.  The name is round 1's (zero insertion + stride-1 correlation)."""
+
+    def forward(self, x: Tensor) -> Tensor:
+        k, op = self.kernel_size[0], self.output_padding[0]
+        if self.stride == (2, 2) and k % 2 == 1 and op == 1 and k == self.kernel_size[1]:
+            return self._forward_with(x, F.pad(self.weight, (0, 1, 0, 1)), k + 1, 0)
+        return _ConvTranspose2d.forward(self, x)
+
+
+class _SubsampledConv2d(_StridedConv2d):
+    """Conv2d(k, stride 2, (k-1)//2) of blur_conv_down (nvidia_ops.py:116-122).  Odd k: a zero row and column make the
+    kernel even, and the layer runs as space-to-depth + a stride-1 valid convolution (common._StridedConv2d) instead of a
+    stride-1 convolution whose result is subsampled (4x the products).  The name is round 1's."""
 
     def forward(self, x: Tensor) -> Tensor:
         k = self.kernel_size[0]
-        p = self.padding[0]
-        op = self.output_padding[0]
-        x = to_act(x)
-        one = torch.ones(1, 1, device=x.device)
-        full = k - 1 - p
-        x = GF.upfirdn2d(x, one, 2, 1, full, full - 1 + op, full, full - 1 + op)
-        w = self.weight.flip(2, 3).transpose(0, 1)
-        y = GF.Conv2dFn.apply(x, w, 0, 0)
-        return GF.affine_act(y, b=self.bias) if self.bias is not None else y
-
-
-class _SubsampledConv2d(nn.Conv2d):
-    """Conv2d(stride 2) = stride-1 correlation + keep every second sample."""
-
-    def forward(self, x: Tensor) -> Tensor:
-        x = to_act(x)
-        y = GF.Conv2dFn.apply(x, self.weight, self.padding[0], self.padding[1])
-        one = torch.ones(1, 1, device=x.device)
-        y = GF.upfirdn2d(y, one, 1, 2, 0, 0, 0, 0)
-        return GF.affine_act(y, b=self.bias) if self.bias is not None else y
+        if self.stride == (2, 2) and k % 2 == 1 and k == self.kernel_size[1] and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0:
+            return self._forward_with(x, F.pad(self.weight, (0, 1, 0, 1)), k + 1)
+        return _StridedConv2d.forward(self, x)
 
 
 def up_conv_blur(in_channels: int, out_channels: int, kernel_size: int, blur_size: Optional[int] = 3):

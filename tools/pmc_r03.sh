@@ -14,11 +14,20 @@ run() {  # name, counters, bench_op args...
 }
 SQ1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY"
 SQ2="SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_WAVES"
-for spec in "wgrad:wgrad 256 128 32 32 128 3" "halo:fwd 256 128 32 32 128 3" "thin64:fwd 256 64 64 64 64 3" "thin16:fwd 256 16 256 256 16 3"; do
+# PMC_SPECS: space-separated subset of the tags below (default: all)
+ALL=("wgrad:wgrad 256 128 32 32 128 3" "halo:fwd 256 128 32 32 128 3" "thin64:fwd 256 64 64 64 64 3" "thin16:fwd 256 16 256 256 16 3")
+TAGS=""
+for spec in "${ALL[@]}"; do
+  tag=${spec%%:*}
+  if [ -n "${PMC_SPECS:-}" ] && [[ " $PMC_SPECS " != *" $tag "* ]]; then continue; fi
+  TAGS="$TAGS $tag"
+done
+for spec in "${ALL[@]}"; do
+  if [[ " $TAGS " != *" ${spec%%:*} "* ]]; then continue; fi
   tag=${spec%%:*}; args=${spec#*:}
   run ${tag}_sq1 "$SQ1" $args && run ${tag}_sq2 "$SQ2" $args && run ${tag}_fetch "FETCH_SIZE" $args && run ${tag}_write "WRITE_SIZE" $args && run ${tag}_grbm "GRBM_GUI_ACTIVE" $args || exit 1
 done
-for tag in wgrad halo thin64 thin16; do
+for tag in $TAGS; do
   echo "=== $tag"
   for p in sq1 sq2 fetch write grbm; do python3 tools/pmc_summary.py "$OUT/${tag}_$p" conv_; done
 done > "$OUT/summary.txt"
