@@ -57,6 +57,9 @@ __device__ __forceinline__ bf16x8 tr_frag2(const char* plo, const char* phi) {
     return f;
 }
 
+#ifndef GAN_TW_KS_UNROLL
+#define GAN_TW_KS_UNROLL 4
+#endif
 #ifndef GAN_TW_LOADERS
 #define GAN_TW_LOADERS 4
 #endif
@@ -143,7 +146,7 @@ __global__ void __launch_bounds__(BIAS ? TW_THREADS : TW_THREADS - 64) conv_wgra
         // producers, not the MFMAs, set the pace: 2 -> 4 producer waves gave 1.3-1.5x).
         constexpr int NSX = (nxc + PL - 1) / PL, NSG = (128 * 8 + PL - 1) / PL, NSLOT = NSX + NSG;
         constexpr int U = MOD ? 7 : NSLOT;  // loads in flight per lane and batch
-        int packed[NSLOT], dsto[NSLOT], rel[NSLOT];
+        int packed[NSLOT], dsto[NSLOT], rel[NSLOT], cls[NSLOT];
         const int c8l = (ltid >> 3) & 7;  // channel chunk: the same for every slot of a lane
         const int cix = ci0 + c8l * 8, cog = co0 + c8l * 8;
         const int shx = p.up2, shg = p.fu.gy_up2;
@@ -172,6 +175,17 @@ __global__ void __launch_bounds__(BIAS ? TW_THREADS : TW_THREADS - 64) conv_wgra
             }
             packed[sl] = yy | (xx << 8) | (bb << 16) | (okc << 25);
             dsto[sl] = d;
+            // when the tiles divide the map (`regular` below), a slot's validity is a STATIC class tested against four
+            // per-tile flags: bit 0 / 1 = outside the image when the tile touches the top / bottom edge, bit 2 / 3 = left /
+            // right edge, bit 4 = never valid (channel or chunk past the tile)
+            int c = okc ? 0 : 16;
+            if (isx) {
+                if (yy < p.py) c |= 1;
+                if (yy >= (p.Hl - p.Ho) + TH + p.py) c |= 2;
+                if (xx < p.px) c |= 4;
+                if (xx >= (p.Wl - p.Wo) + TW + p.px) c |= 8;
+            }
+            cls[sl] = c;
         }
         auto origin = [&](const int t, int& n0, int& oy0, int& ox0) {
             if (NB == 1) {
@@ -190,11 +204,25 @@ __global__ void __launch_bounds__(BIAS ? TW_THREADS : TW_THREADS - 64) conv_wgra
             // barrier, and stay in flight in registers while the producers wait for the consumers: the memory latency
             // of a tile no longer sits between two barriers (a tile took ~5700 cycles for 2300 of MFMA work).
             v4u v[NSLOT];
+            // tiles that divide the map and the batch: ~4 VALU instructions per chunk instead of ~27 (PMC, round 3: the
+            // producers' 350 VALU instructions per tile, issued on SIMDs whose vector issue the consumers' MFMAs hold
+            // half of the time, paced the kernel: 44 % MFMA utilisation with no wait on memory)
+            const bool regular = p.Ho % TH == 0 && p.Wo % TW == 0 && (NB == 1 || p.N % NB == 0);
             auto issue = [&](const int t) {
                 int n0, oy0, ox0;
                 origin(t, n0, oy0, ox0);
                 const int bx = ((n0 * p.H + (oy0 >> shx)) * p.W + (ox0 >> shx)) * p.Cin * 2;
                 const int bg = ((n0 * Hg + (oy0 >> shg)) * Wg + (ox0 >> shg)) * p.Cout * 2;
+                if (regular) {
+                    const int flags = 16 | (oy0 == 0 ? 1 : 0) | (oy0 + TH == p.Ho ? 2 : 0) | (ox0 == 0 ? 4 : 0) | (ox0 + TW == p.Wo ? 8 : 0);
+#pragma unroll
+                    for (int k = 0; k < NSLOT; ++k) {
+                        const bool isx = k < NSX;
+                        const unsigned off = (cls[k] & flags) ? INV : (unsigned)((isx ? bx : bg) + rel[k]);
+                        v[k] = __builtin_amdgcn_raw_buffer_load_b128(isx ? rx : rg, off, 0, 0);
+                    }
+                    return;
+                }
 #pragma unroll
                 for (int k = 0; k < NSLOT; ++k) {
                     const bool isx = k < NSX;
@@ -287,6 +315,10 @@ __global__ void __launch_bounds__(BIAS ? TW_THREADS : TW_THREADS - 64) conv_wgra
         // tile is 144 MFMAs on each of four SIMDs instead of 192 on three, the accumulators are 144 registers (were
         // 192), and every wave stores its own columns of every tap.)
         f32x4 acc[NT * NT][4];
+        // K steps unrolled: the next step's fragment reads go out under this step's MFMAs (rolled, a tile exposed four LDS
+        // latencies: 84 -> 79 us on 128 ch @ 32x32, 103 -> 83 us on 256 ch @ 16x16).  Not with the bias wave: nine waves
+        // cap the registers at 168.  (Measured, not kept: s_setprio 2 for the consumers -- no change on nine shapes.)
+        constexpr int KSU = BIAS ? 1 : GAN_TW_KS_UNROLL;
 #pragma unroll
         for (int j = 0; j < NT * NT; ++j)
 #pragma unroll
@@ -295,7 +327,7 @@ __global__ void __launch_bounds__(BIAS ? TW_THREADS : TW_THREADS - 64) conv_wgra
             __syncthreads();  // tile t is in its stage
             const char* const xl = tw_lds + ((t - t0) & 1) * BUF + wave * PLX;
             const char* const gl = tw_lds + ((t - t0) & 1) * BUF + 4 * PLX;
-#pragma unroll 1
+#pragma unroll KSU
             for (int ks = 0; ks < 4; ++ks) {
                 const int Plo = ks * 32 + 4 * g + q, Phi = Plo + 16;
                 bf16x8 a[4];
