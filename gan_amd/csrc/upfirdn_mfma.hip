@@ -15,6 +15,8 @@
 // ds_read_b64_tr_b16 (the k <-> pixel map of conv_thin_wgrad.hip); D comes out as 4 consecutive
 // channels of one pixel per lane -> 8-byte stores, 512 contiguous bytes per wave at C = 16.
 #include "common.h"
+#include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -85,9 +87,11 @@ __global__ void __launch_bounds__(256, U <= 6 ? 4 : 3) upfirdn2d_mfma_k(const Fi
         const int rem = (int)(t - img * tiles_per_cb);
         n = (int)(img / p.ncb);
         cb = (int)(img - (int64_t)n * p.ncb);
-        const int ty = rem / p.tiles_x;
-        oy0 = ty * p.TH;
-        ox0 = (rem - ty * p.tiles_x) * 32;
+        // column-major walk: a workgroup's consecutive tiles are vertical neighbours, so the halo rows a tile shares with
+        // the one above it were read by this CU moments ago (L2) instead of by another workgroup on another XCD
+        const int tx = rem / p.tiles_y;
+        oy0 = (rem - tx * p.tiles_y) * p.TH;
+        ox0 = tx * 32;
     };
     // Input region (zero outside the image and in the columns that only meet zero taps) -> registers -> LDS.
     // `issue` starts the loads of a tile's region (branch-free buffer loads: chunks outside the image read
@@ -189,6 +193,187 @@ __global__ void __launch_bounds__(256, U <= 6 ? 4 : 3) upfirdn2d_mfma_k(const Fi
     }
 }
 
+
+// ---- the same kernel with its geometry at compile time (round 3) -----------------------------------------------------
+// PMC on the kernel above: ~750 VALU instructions per wave and tile against 48 MFMAs -- chunk decoding with run-time
+// shifts and a reciprocal multiply per load, fragment addresses per (fragment, tap row), 64-bit store addresses -- as
+// much issue time as the tile's bytes take at HBM rate, so the op ran at ~0.45 of 8 TB/s with the memory system half idle.
+// Here stride 1 (down = 1), taps <= 4 rows and the channel grouping are template parameters:
+//   * a lane's chunks of the input region are decoded ONCE (byte offset from the region's origin, LDS slot, packed
+//     (row, column)); per tile a chunk costs five VALU instructions: packed 16-bit subtract / max / compare against the
+//     tile's wave-uniform valid (row, column) window, an add and a select;
+//   * fragment addresses are lane base + an instruction immediate (without upsampling; with it, one scalar per row);
+//   * stores are buffer stores at lane offset + scalar offset, the ragged-edge test one compare and one select.
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+
+template <int UPL, int KY, int NCGL>
+struct FirFastCfg {
+    static constexpr int up = 1 << UPL, ncg = 1 << NCGL, TH = 16 >> NCGL, RPW = 4 >> NCGL, XSTEP = 16 >> UPL, RWR = 32 + XSTEP;
+    static constexpr int RH = (TH - 1 + KY - 1) / up + 2, NPX = RH * RWR, PL = NPX * 32, SH = NCGL + 4;
+    static constexpr int NCHUNK = ((NPX + 7) >> 3) * 8 * 2 * ncg, U = (NCHUNK + 255) / 256;
+    static constexpr int FULL = ((NPX >> 3) * 8 * 2 * ncg) / 256;  // slots whose 256 chunks all lie inside the region
+    static constexpr int LDS = KY * 2048 + ncg * PL;
+};
+
+template <int UPL, int KY, int NCGL>
+__global__ void __launch_bounds__(256, (FirFastCfg<UPL, KY, NCGL>::U <= 6 ? 4 : 3)) upfirdn2d_fast_k(const FirArgs p) {
+    typedef FirFastCfg<UPL, KY, NCGL> C;
+    constexpr int up = C::up, ncg = C::ncg, TH = C::TH, RPW = C::RPW, XSTEP = C::XSTEP, RWR = C::RWR, RH = C::RH, NPX = C::NPX, PL = C::PL;
+    constexpr int SH = C::SH, U = C::U;
+    extern __shared__ __attribute__((aligned(256))) char fir_lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
+    char* const toep = fir_lds;              // [KY][hi, lo][64 lanes][16 B]
+    char* const reg = fir_lds + KY * 2048;   // [ncg][RH * RWR pixels][32 B]
+
+    // ---- banded tap matrices, in MFMA B-fragment order (once per workgroup) ------------------------
+    const int J0 = p.px1 & (up - 1);
+    for (int e = tid; e < KY * 64; e += 256) {
+        const int l = e & 63, i = e >> 6;
+        const int xo = l & 15, gg = l >> 4;
+        bf16x8 hi, lo;
+#pragma unroll
+        for (int j8 = 0; j8 < 8; ++j8) {
+            const int xrel = j8 < 4 ? 4 * gg + j8 : 16 + 4 * gg + j8 - 4;
+            const int j = xrel * up - xo + J0;
+            const float t = (j >= 0 && j < p.kx) ? p.taps[i * p.kx + j] : 0.f;
+            hi[j8] = (bf16)t;
+            lo[j8] = (bf16)(t - (float)hi[j8]);
+        }
+        char* dst = toep + (i * 2) * 1024 + l * 16;
+        *reinterpret_cast<bf16x8*>(dst) = hi;
+        *reinterpret_cast<bf16x8*>(dst + 1024) = lo;
+    }
+
+    const int64_t t0 = p.ntiles * blockIdx.x / gridDim.x;
+    const int64_t t1 = p.ntiles * (blockIdx.x + 1) / gridDim.x;
+    const int tiles_per_cb = p.tiles_x * p.tiles_y;
+    auto decode = [&](int64_t t, int& n, int& cb, int& oy0, int& ox0) {
+        const int64_t img = t / tiles_per_cb;
+        const int rem = (int)(t - img * tiles_per_cb);
+        n = (int)(img / p.ncb);
+        cb = (int)(img - (int64_t)n * p.ncb);
+        const int tx = rem / p.tiles_y;  // column-major walk: consecutive tiles are vertical neighbours
+        oy0 = (rem - tx * p.tiles_y) * TH;
+        ox0 = tx * 32;
+    };
+
+    // ---- this lane's chunks of the region, decoded once ------------------------------------------------
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    constexpr unsigned INV = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p.x), 0, p.x_bytes, 0x00020000);
+    unsigned ryx[U];   // (row << 16) | column of the chunk's pixel in the region; 0xffffffff where no tile has it
+    int soff[U], ldso[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int idx = u * 256 + tid;
+        const int p8 = idx >> SH, r8 = idx & ((1 << SH) - 1);
+        const int c8 = r8 >> 3;
+        const int pix = p8 * 8 + (r8 & 7);
+        const int ry = pix / RWR, rxx = pix - ry * RWR;
+        ryx[u] = (pix < NPX && rxx < p.ncols) ? ((unsigned)ry << 16 | (unsigned)rxx) : 0xffffffffu;
+        soff[u] = ((ry * p.W + rxx) * p.C + c8 * 8) * 2;
+        ldso[u] = pix < NPX ? (c8 >> 1) * PL + pix * 32 + (c8 & 1) * 16 : -1;
+    }
+    v4u pre[U];
+    auto issue = [&](int n, int cb, int oy0, int ox0) {
+        const int iy0 = (oy0 - p.py1 + up - 1) >> UPL;
+        const int ix0 = (ox0 - p.px1 + up - 1) >> UPL;
+        const int iy1 = (oy0 + TH - 1 - p.py1 + KY - 1) >> UPL;
+        // the window of region (row, column) that lies inside the image and inside this tile's rows: wave-uniform
+        int rlo = iy0 < 0 ? -iy0 : 0, rhi = min(iy1 - iy0, p.H - 1 - iy0);
+        int xlo = ix0 < 0 ? -ix0 : 0, xhi = min(RWR - 1, p.W - 1 - ix0);
+        if (rhi < rlo || xhi < xlo) { rlo = 0x7fff; rhi = 0x7fff; xlo = 0; xhi = 0; }
+        const unsigned lo_u = (unsigned)rlo << 16 | (unsigned)xlo, rng_u = (unsigned)(rhi - rlo) << 16 | (unsigned)(xhi - xlo);
+        const us2 lo_pk = __builtin_bit_cast(us2, lo_u), rng_pk = __builtin_bit_cast(us2, rng_u);
+        const int base = (((n * p.H + iy0) * p.W + ix0) * p.C + cb * ncg * 16) * 2;  // may be negative: valid lanes add enough
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const us2 d = __builtin_bit_cast(us2, ryx[u]) - lo_pk;  // wraps to a large value below the window
+            const us2 m = __builtin_elementwise_max(d, rng_pk);
+            const bool ok = __builtin_bit_cast(unsigned, m) == rng_u;
+            pre[u] = __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? (unsigned)(base + soff[u]) : INV, 0, 0);
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (u < C::FULL || ldso[u] >= 0) *reinterpret_cast<v4u*>(reg + ldso[u]) = pre[u];  // (cells outside the window get zeros)
+        }
+    };
+
+    // fragment base: this lane's (pixel, channel quad) of a 32-pixel K block, + the wave's first output row without upsampling
+    const int lane_off = (4 * g + q) * 32 + pp * 8 + (UPL == 0 ? wave * RPW * RWR * 32 : 0);
+    const int st_lane = (li * p.C + 4 * g) * 2;  // this lane's bytes inside a fragment's 16 pixels x 16 channels of y
+    const unsigned img_bytes = (unsigned)(p.Ho * p.Wo * p.C * 2);
+    if (t0 < t1) {
+        int n, cb, oy0, ox0;
+        decode(t0, n, cb, oy0, ox0);
+        issue(n, cb, oy0, ox0);
+    }
+    for (int64_t t = t0; t < t1; ++t) {
+        int n, cb, oy0, ox0;
+        decode(t, n, cb, oy0, ox0);
+        __syncthreads();  // previous tile's fragment reads (and the tap matrices' stores) are done
+        commit();
+        __syncthreads();
+        if (t + 1 < t1) {
+            int n2, cb2, oy2, ox2;
+            decode(t + 1, n2, cb2, oy2, ox2);
+            issue(n2, cb2, oy2, ox2);
+        }
+        f32x4 acc[8];
+#pragma unroll
+        for (int f = 0; f < 8; ++f) acc[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // Fragment (f, tap row i) reads region row fr + i (no upsampling), or -- with 2x zero insertion -- only when
+        // fr + i + wpar is even, row rbase + (fr + i + wpar) / 2: wpar (the parity of the wave's first output row minus the
+        // pad) is the same for every tile of the launch, so which (f, i) pairs exist is decided by ONE wave-uniform branch
+        // around two compile-time bodies, and every address is lane base + immediate.
+        auto compute = [&](auto wparc, const int frag_base) {
+            constexpr int WPAR = decltype(wparc)::value;
+#pragma unroll
+            for (int i = 0; i < KY; ++i) {
+                const char* tp = toep + (i * 2) * 1024 + lane * 16;
+                const bf16x8 bhi = *reinterpret_cast<const bf16x8*>(tp);
+                const bf16x8 blo = *reinterpret_cast<const bf16x8*>(tp + 1024);
+#pragma unroll
+                for (int f = 0; f < 8; ++f) {
+                    const int cgi = f & (ncg - 1), fx = (f >> NCGL) & 1, fr = f >> (NCGL + 1);
+                    if (UPL == 1 && ((fr + i + WPAR) & 1)) continue;  // (compile-time) this tap row falls on inserted zeros
+                    const int row = UPL == 0 ? fr + i : (fr + i + WPAR) >> 1;
+                    const bf16x8 a = fir_tr_frag(reg + frag_base + cgi * PL + (row * RWR + fx * XSTEP) * 32);
+                    acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bhi, acc[f], 0, 0, 0);
+                    acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, blo, acc[f], 0, 0, 0);
+                }
+            }
+        };
+        if constexpr (UPL == 0) {
+            compute(std::integral_constant<int, 0>{}, lane_off);
+        } else {
+            const int E = oy0 - p.py1 + wave * RPW, wpar = E & 1;
+            const int rbase = ((E - wpar) >> 1) - ((oy0 - p.py1 + 1) >> 1);  // >= 0: the region starts at the tile's first tap row
+            if (wpar) compute(std::integral_constant<int, 1>{}, lane_off + rbase * (RWR * 32));
+            else compute(std::integral_constant<int, 0>{}, lane_off + rbase * (RWR * 32));
+        }
+        // D: row = channel 4g + r, col = output pixel li -> 8-byte buffer stores into image n (a resource per image: outputs
+        // may exceed 2^31 bytes in all)
+        const __amdgpu_buffer_rsrc_t ry_ = __builtin_amdgcn_make_buffer_rsrc(p.y + (int64_t)n * p.Ho * p.Wo * p.C, 0, img_bytes, 0x00020000);
+#pragma unroll
+        for (int f = 0; f < 8; ++f) {
+            const int cgi = f & (ncg - 1), fx = (f >> NCGL) & 1, fr = f >> (NCGL + 1);
+            const int oy = oy0 + wave * RPW + fr;                       // wave-uniform
+            const int wlim = oy < p.Ho ? p.Wo - ox0 - 16 * fx : 0;      // pixels of this fragment inside the image
+            const int sbase = ((oy * p.Wo + ox0 + 16 * fx) * p.C + (cb * ncg + cgi) * 16) * 2;
+            bf16x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = (bf16)acc[f][r];
+            typedef unsigned v2u_ __attribute__((ext_vector_type(2)));
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u_, o), ry_, li < wlim ? (unsigned)st_lane : INV, sbase, 0);
+        }
+    }
+}
+
 }  // namespace
 
 // 1 = served, 0 = shape not eligible (caller falls back to the VALU kernels), < 0 = error.
@@ -222,6 +407,7 @@ int gan_upfirdn2d_mfma(const void* x, const float* taps, void* y, int N, int H, 
         if (ncg_log2 == 0) return 0;
     }
     a.ncg_log2 = ncg_log2;
+    const bool fast = down == 1 && a.KC == 1 && ky >= 2 && ky <= 4 && (int64_t)Ho * Wo * C * 2 < (1LL << 31) && !(getenv("GAN_AMD_FIR_OLD") && getenv("GAN_AMD_FIR_OLD")[0] == '1');
     a.tiles_x = (Wo + 31) / 32;
     a.tiles_y = (Ho + a.TH - 1) / a.TH;
     a.ncb = C / 16 >> ncg_log2;
@@ -231,6 +417,44 @@ int gan_upfirdn2d_mfma(const void* x, const float* taps, void* y, int N, int H, 
     int64_t grid = 256LL * per_cu;
     if (grid > a.ntiles) grid = a.ntiles;
     a.x_bytes = (unsigned)((int64_t)N * H * W * C * 2);
+    if (fast) {
+#define FIR_FAST(UPL_, KY_, NCGL_)                                                                                          \
+    do {                                                                                                                    \
+        if constexpr (FirFastCfg<UPL_, KY_, NCGL_>::U <= 9 && FirFastCfg<UPL_, KY_, NCGL_>::LDS <= 40 * 1024) {             \
+            if (FirFastCfg<UPL_, KY_, NCGL_>::LDS != lds || FirFastCfg<UPL_, KY_, NCGL_>::TH != a.TH) {                     \
+                gan_set_error("upfirdn2d(mfma): plan mismatch");                                                            \
+                return GAN_ERR_ARG;                                                                                         \
+            }                                                                                                               \
+            hipLaunchKernelGGL((upfirdn2d_fast_k<UPL_, KY_, NCGL_>), dim3((unsigned)grid), dim3(256), (size_t)lds, st, a); \
+        } else {                                                                                                            \
+            gan_set_error("upfirdn2d(mfma): plan mismatch");                                                                \
+            return GAN_ERR_ARG;                                                                                             \
+        }                                                                                                                   \
+    } while (0)
+#define FIR_FAST_KY(UPL_, NCGL_)                      \
+    do {                                              \
+        if (ky == 2) FIR_FAST(UPL_, 2, NCGL_);        \
+        else if (ky == 3) FIR_FAST(UPL_, 3, NCGL_);   \
+        else FIR_FAST(UPL_, 4, NCGL_);                \
+    } while (0)
+        if (up == 1) {
+            if (ncg_log2 == 2) FIR_FAST_KY(0, 2);
+            else if (ncg_log2 == 1) FIR_FAST_KY(0, 1);
+            else FIR_FAST_KY(0, 0);
+        } else {
+            if (ncg_log2 == 2) FIR_FAST_KY(1, 2);
+            else if (ncg_log2 == 1) FIR_FAST_KY(1, 1);
+            else FIR_FAST_KY(1, 0);
+        }
+#undef FIR_FAST_KY
+#undef FIR_FAST
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) {
+            gan_set_error("upfirdn2d(mfma, fast): launch failed: %s", hipGetErrorString(e));
+            return GAN_ERR_LAUNCH;
+        }
+        return 1;
+    }
     const int nchunk_max = ((a.RHmax * a.RWr + 7) >> 3) * 8 * (2 << ncg_log2);
     const int slots = (nchunk_max + 255) / 256;
     if (slots <= 4)
