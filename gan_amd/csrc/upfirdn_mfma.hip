@@ -250,11 +250,14 @@ __global__ void __launch_bounds__(256, (FirFastCfg<UPL, KY, NCGL>::U <= 6 ? 4 : 
     const int64_t t1 = p.ntiles * (blockIdx.x + 1) / gridDim.x;
     const int tiles_per_cb = p.tiles_x * p.tiles_y;
     auto decode = [&](int64_t t, int& n, int& cb, int& oy0, int& ox0) {
+        // column-major walk inside (image, channel block): consecutive tiles are vertical neighbours and share halo rows
+        // (measured, not kept: the channel blocks of a column next to each other in the walk, or the block fastest --
+        // 15-25 % slower at 64 / 128 channels, a few % faster at 256 / 512)
         const int64_t img = t / tiles_per_cb;
         const int rem = (int)(t - img * tiles_per_cb);
         n = (int)(img / p.ncb);
         cb = (int)(img - (int64_t)n * p.ncb);
-        const int tx = rem / p.tiles_y;  // column-major walk: consecutive tiles are vertical neighbours
+        const int tx = rem / p.tiles_y;
         oy0 = (rem - tx * p.tiles_y) * TH;
         ox0 = tx * 32;
     };
@@ -305,7 +308,10 @@ __global__ void __launch_bounds__(256, (FirFastCfg<UPL, KY, NCGL>::U <= 6 ? 4 : 
 
     // fragment base: this lane's (pixel, channel quad) of a 32-pixel K block, + the wave's first output row without upsampling
     const int lane_off = (4 * g + q) * 32 + pp * 8 + (UPL == 0 ? wave * RPW * RWR * 32 : 0);
-    const int st_lane = (li * p.C + 4 * g) * 2;  // this lane's bytes inside a fragment's 16 pixels x 16 channels of y
+    // after the fragment-pair swap of the epilogue: lane (g, li) holds channels 8 (g >> 1) .. + 7 of pixel li + 16 (g & 1)
+    // (pair = two channel groups: channels 16 (g & 1) + 8 (g >> 1) .. + 7 of pixel li)
+    const int st_pix = NCGL >= 1 ? li : li + 16 * (g & 1);
+    const int st_lane = (st_pix * p.C + (NCGL >= 1 ? 16 * (g & 1) : 0) + 8 * (g >> 1)) * 2;
     const unsigned img_bytes = (unsigned)(p.Ho * p.Wo * p.C * 2);
     if (t0 < t1) {
         int n, cb, oy0, ox0;
@@ -359,17 +365,35 @@ __global__ void __launch_bounds__(256, (FirFastCfg<UPL, KY, NCGL>::U <= 6 ? 4 : 
         // D: row = channel 4g + r, col = output pixel li -> 8-byte buffer stores into image n (a resource per image: outputs
         // may exceed 2^31 bytes in all)
         const __amdgpu_buffer_rsrc_t ry_ = __builtin_amdgcn_make_buffer_rsrc(p.y + (int64_t)n * p.Ho * p.Wo * p.C, 0, img_bytes, 0x00020000);
+        // Fragment pairs: v_permlane16_swap trades the odd 16-lane rows' results of the first fragment for the even rows'
+        // results of the second, after which a lane holds 8 consecutive channels of ONE pixel -- 16-byte stores, half as
+        // many.  The pair is two adjacent channel groups of the same 16 pixels where the tile has them (a store instruction
+        // then writes 64 contiguous bytes per pixel), else the two x halves of a row (C = 16: 32 pixels x 32 bytes, contiguous).
+        constexpr bool PAIR_CG = NCGL >= 1;
+        constexpr int F2 = PAIR_CG ? 1 : (1 << NCGL);
 #pragma unroll
         for (int f = 0; f < 8; ++f) {
+            if (f & F2) continue;
             const int cgi = f & (ncg - 1), fx = (f >> NCGL) & 1, fr = f >> (NCGL + 1);
-            const int oy = oy0 + wave * RPW + fr;                       // wave-uniform
-            const int wlim = oy < p.Ho ? p.Wo - ox0 - 16 * fx : 0;      // pixels of this fragment inside the image
+            const int oy = oy0 + wave * RPW + fr;                                  // wave-uniform
+            const int wlim = oy < p.Ho ? p.Wo - ox0 - 16 * fx : 0;                 // pixels of the pair inside the image
             const int sbase = ((oy * p.Wo + ox0 + 16 * fx) * p.C + (cb * ncg + cgi) * 16) * 2;
-            bf16x4 o;
+            bf16x4 oa, ob;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = (bf16)acc[f][r];
+            for (int r = 0; r < 4; ++r) {
+                oa[r] = (bf16)acc[f][r];
+                ob[r] = (bf16)acc[f + F2][r];
+            }
             typedef unsigned v2u_ __attribute__((ext_vector_type(2)));
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u_, o), ry_, li < wlim ? (unsigned)st_lane : INV, sbase, 0);
+            v2u_ xa = __builtin_bit_cast(v2u_, oa), xb = __builtin_bit_cast(v2u_, ob);
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+                const auto sw = __builtin_amdgcn_permlane16_swap(xa[d], xb[d], false, false);
+                xa[d] = sw[0];
+                xb[d] = sw[1];
+            }
+            const v4u o = {xa[0], xa[1], xb[0], xb[1]};
+            __builtin_amdgcn_raw_buffer_store_b128(o, ry_, st_pix < wlim ? (unsigned)st_lane : INV, sbase, 0);
         }
     }
 }
@@ -394,6 +418,7 @@ int gan_upfirdn2d_mfma(const void* x, const float* taps, void* y, int N, int H, 
     a.RWr = 32 * a.KC + a.xstep;
     a.ncols = a.xstep + kneed + 1;
     a.rw_magic = (unsigned)((0x100000000ULL + a.RWr - 1) / a.RWr);
+    const bool fast = (((uintptr_t)y) & 15) == 0 && down == 1 && a.KC == 1 && ky >= 2 && ky <= 4 && (int64_t)Ho * Wo * C * 2 < (1LL << 31) && !(getenv("GAN_AMD_FIR_OLD") && getenv("GAN_AMD_FIR_OLD")[0] == '1');
     int lds = 0;
     int ncg_log2 = 2;
     for (;; --ncg_log2) {
@@ -402,25 +427,27 @@ int gan_upfirdn2d_mfma(const void* x, const float* taps, void* y, int N, int H, 
             a.TH = 16 >> ncg_log2;
             a.RHmax = ((a.TH - 1) * down + ky - 1) / up + 2;
             lds = ky * a.KC * 2048 + ncg * a.RHmax * a.RWr * 32;
-            if (lds <= 40 * 1024) break;  // >= 4 workgroups per CU: their load / MFMA phases overlap
+            // >= 4 workgroups per CU (their load / MFMA phases overlap); four channel groups = whole 128-byte lines of a
+            // >= 64-channel pixel are worth a third workgroup less (the fast kernel; half lines ran at 0.7x the rate)
+            if (lds <= 40 * 1024 || (fast && ncg == 4 && lds <= 52 * 1024)) break;
         }
         if (ncg_log2 == 0) return 0;
     }
     a.ncg_log2 = ncg_log2;
-    const bool fast = down == 1 && a.KC == 1 && ky >= 2 && ky <= 4 && (int64_t)Ho * Wo * C * 2 < (1LL << 31) && !(getenv("GAN_AMD_FIR_OLD") && getenv("GAN_AMD_FIR_OLD")[0] == '1');
     a.tiles_x = (Wo + 31) / 32;
     a.tiles_y = (Ho + a.TH - 1) / a.TH;
     a.ncb = C / 16 >> ncg_log2;
     a.ntiles = (int64_t)a.tiles_x * a.tiles_y * a.ncb * N;
     int per_cu = (160 * 1024) / lds;
     if (per_cu > 4) per_cu = 4;
+    if (fast && lds > 40 * 1024) per_cu = 3;
     int64_t grid = 256LL * per_cu;
     if (grid > a.ntiles) grid = a.ntiles;
     a.x_bytes = (unsigned)((int64_t)N * H * W * C * 2);
     if (fast) {
 #define FIR_FAST(UPL_, KY_, NCGL_)                                                                                          \
     do {                                                                                                                    \
-        if constexpr (FirFastCfg<UPL_, KY_, NCGL_>::U <= 9 && FirFastCfg<UPL_, KY_, NCGL_>::LDS <= 40 * 1024) {             \
+        if constexpr (FirFastCfg<UPL_, KY_, NCGL_>::U <= 11 && FirFastCfg<UPL_, KY_, NCGL_>::LDS <= 52 * 1024) {             \
             if (FirFastCfg<UPL_, KY_, NCGL_>::LDS != lds || FirFastCfg<UPL_, KY_, NCGL_>::TH != a.TH) {                     \
                 gan_set_error("upfirdn2d(mfma): plan mismatch");                                                            \
                 return GAN_ERR_ARG;                                                                                         \
