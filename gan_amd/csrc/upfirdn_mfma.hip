@@ -206,9 +206,11 @@ __global__ void __launch_bounds__(256, U <= 6 ? 4 : 3) upfirdn2d_mfma_k(const Fi
 //   * stores are buffer stores at lane offset + scalar offset, the ragged-edge test one compare and one select.
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 
-template <int UPL, int KY, int NCGL>
+// RX: rows per wave x RX (8 RX fragments per wave).  (Measured, not kept: RX = 2 under upsampling, where a tile's region is a
+// quarter of its output -- 16 accumulators and the wider store phase cost occupancy: 3.2 -> 2.0 TB/s.)
+template <int UPL, int KY, int NCGL, int RX = 1>
 struct FirFastCfg {
-    static constexpr int up = 1 << UPL, ncg = 1 << NCGL, TH = 16 >> NCGL, RPW = 4 >> NCGL, XSTEP = 16 >> UPL, RWR = 32 + XSTEP;
+    static constexpr int up = 1 << UPL, ncg = 1 << NCGL, TH = (16 >> NCGL) * RX, RPW = (4 >> NCGL) * RX, NF = 8 * RX, XSTEP = 16 >> UPL, RWR = 32 + XSTEP;
     static constexpr int RH = (TH - 1 + KY - 1) / up + 2, NPX = RH * RWR, PL = NPX * 32, SH = NCGL + 4;
     static constexpr int NCHUNK = ((NPX + 7) >> 3) * 8 * 2 * ncg, U = (NCHUNK + 255) / 256;
     static constexpr int FULL = ((NPX >> 3) * 8 * 2 * ncg) / 256;  // slots whose 256 chunks all lie inside the region
@@ -219,7 +221,7 @@ template <int UPL, int KY, int NCGL>
 __global__ void __launch_bounds__(256, (FirFastCfg<UPL, KY, NCGL>::U <= 6 ? 4 : 3)) upfirdn2d_fast_k(const FirArgs p) {
     typedef FirFastCfg<UPL, KY, NCGL> C;
     constexpr int up = C::up, ncg = C::ncg, TH = C::TH, RPW = C::RPW, XSTEP = C::XSTEP, RWR = C::RWR, RH = C::RH, NPX = C::NPX, PL = C::PL;
-    constexpr int SH = C::SH, U = C::U;
+    constexpr int SH = C::SH, U = C::U, NF = C::NF;
     extern __shared__ __attribute__((aligned(256))) char fir_lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -329,9 +331,9 @@ __global__ void __launch_bounds__(256, (FirFastCfg<UPL, KY, NCGL>::U <= 6 ? 4 : 
             decode(t + 1, n2, cb2, oy2, ox2);
             issue(n2, cb2, oy2, ox2);
         }
-        f32x4 acc[8];
+        f32x4 acc[NF];
 #pragma unroll
-        for (int f = 0; f < 8; ++f) acc[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int f = 0; f < NF; ++f) acc[f] = f32x4{0.f, 0.f, 0.f, 0.f};
         // Fragment (f, tap row i) reads region row fr + i (no upsampling), or -- with 2x zero insertion -- only when
         // fr + i + wpar is even, row rbase + (fr + i + wpar) / 2: wpar (the parity of the wave's first output row minus the
         // pad) is the same for every tile of the launch, so which (f, i) pairs exist is decided by ONE wave-uniform branch
@@ -344,7 +346,7 @@ __global__ void __launch_bounds__(256, (FirFastCfg<UPL, KY, NCGL>::U <= 6 ? 4 : 
                 const bf16x8 bhi = *reinterpret_cast<const bf16x8*>(tp);
                 const bf16x8 blo = *reinterpret_cast<const bf16x8*>(tp + 1024);
 #pragma unroll
-                for (int f = 0; f < 8; ++f) {
+                for (int f = 0; f < NF; ++f) {
                     const int cgi = f & (ncg - 1), fx = (f >> NCGL) & 1, fr = f >> (NCGL + 1);
                     if (UPL == 1 && ((fr + i + WPAR) & 1)) continue;  // (compile-time) this tap row falls on inserted zeros
                     const int row = UPL == 0 ? fr + i : (fr + i + WPAR) >> 1;
@@ -372,7 +374,7 @@ __global__ void __launch_bounds__(256, (FirFastCfg<UPL, KY, NCGL>::U <= 6 ? 4 : 
         constexpr bool PAIR_CG = NCGL >= 1;
         constexpr int F2 = PAIR_CG ? 1 : (1 << NCGL);
 #pragma unroll
-        for (int f = 0; f < 8; ++f) {
+        for (int f = 0; f < NF; ++f) {
             if (f & F2) continue;
             const int cgi = f & (ncg - 1), fx = (f >> NCGL) & 1, fr = f >> (NCGL + 1);
             const int oy = oy0 + wave * RPW + fr;                                  // wave-uniform
@@ -424,7 +426,7 @@ int gan_upfirdn2d_mfma(const void* x, const float* taps, void* y, int N, int H, 
     for (;; --ncg_log2) {
         const int ncg = 1 << ncg_log2;
         if ((C / 16) % ncg == 0) {
-            a.TH = 16 >> ncg_log2;
+            a.TH = 16 >> ncg_log2;  // (x FirFastCfg::RX = 1)
             a.RHmax = ((a.TH - 1) * down + ky - 1) / up + 2;
             lds = ky * a.KC * 2048 + ncg * a.RHmax * a.RWr * 32;
             // >= 4 workgroups per CU (their load / MFMA phases overlap); four channel groups = whole 128-byte lines of a
