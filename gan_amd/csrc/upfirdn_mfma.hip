@@ -29,6 +29,7 @@ struct FirArgs {
     int64_t ntiles;
     unsigned rw_magic;  // ceil(2^32 / RWr)
     unsigned x_bytes;   // < 2^31: 32-bit buffer offsets
+    int rowmajor;       // fast kernel: walk the tiles of an (image, channel block) row by row instead of column by column
 };
 
 __device__ __forceinline__ bf16x8 fir_tr_frag(const char* p) {
@@ -212,16 +213,23 @@ template <int UPL, int KY, int NCGL, int RX = 1>
 struct FirFastCfg {
     static constexpr int up = 1 << UPL, ncg = 1 << NCGL, TH = (16 >> NCGL) * RX, RPW = (4 >> NCGL) * RX, NF = 8 * RX, XSTEP = 16 >> UPL, RWR = 32 + XSTEP;
     static constexpr int RH = (TH - 1 + KY - 1) / up + 2, NPX = RH * RWR, PL = NPX * 32, SH = NCGL + 4;
-    static constexpr int NCHUNK = ((NPX + 7) >> 3) * 8 * 2 * ncg, U = (NCHUNK + 255) / 256;
-    static constexpr int FULL = ((NPX >> 3) * 8 * 2 * ncg) / 256;  // slots whose 256 chunks all lie inside the region
+    // Only the columns a tile's taps can reach (square FIR: kx <= KY) are ever loaded: the region's LDS image keeps the
+    // RWR pitch the K blocks of the MFMA need, its other columns are zeroed once per workgroup.
+    static constexpr int NCOLS = XSTEP + (15 + KY - 1) / up + 1, NPC = RH * NCOLS;
+    static constexpr int NCHUNK = ((NPC + 7) >> 3) * 8 * 2 * ncg, U = (NCHUNK + 255) / 256;
+    static constexpr int FULL = ((NPC >> 3) * 8 * 2 * ncg) / 256;  // slots whose 256 chunks all lie inside the region
     static constexpr int LDS = KY * 2048 + ncg * PL;
+    // register sets of region chunks in flight per lane (tiles prefetched): with one, a tile's HBM round trip sat between
+    // two barriers of every iteration (ablation: loads alone 174 us, stores alone 202 us, together 380 us on 32x64x256x256
+    // upsampled: no overlap); two while the registers allow four waves per SIMD
+    static constexpr int PD = U <= 8 ? 2 : 1;
 };
 
 template <int UPL, int KY, int NCGL>
-__global__ void __launch_bounds__(256, (FirFastCfg<UPL, KY, NCGL>::U <= 6 ? 4 : 3)) upfirdn2d_fast_k(const FirArgs p) {
+__global__ void __launch_bounds__(256, (FirFastCfg<UPL, KY, NCGL>::U * FirFastCfg<UPL, KY, NCGL>::PD <= 8 ? 4 : 3)) upfirdn2d_fast_k(const FirArgs p) {
     typedef FirFastCfg<UPL, KY, NCGL> C;
     constexpr int up = C::up, ncg = C::ncg, TH = C::TH, RPW = C::RPW, XSTEP = C::XSTEP, RWR = C::RWR, RH = C::RH, NPX = C::NPX, PL = C::PL;
-    constexpr int SH = C::SH, U = C::U, NF = C::NF;
+    constexpr int SH = C::SH, U = C::U, NF = C::NF, NCOLS = C::NCOLS, NPC = C::NPC, PD = C::PD;
     extern __shared__ __attribute__((aligned(256))) char fir_lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -231,6 +239,7 @@ __global__ void __launch_bounds__(256, (FirFastCfg<UPL, KY, NCGL>::U <= 6 ? 4 : 
 
     // ---- banded tap matrices, in MFMA B-fragment order (once per workgroup) ------------------------
     const int J0 = p.px1 & (up - 1);
+    int my_lo = 0;
     for (int e = tid; e < KY * 64; e += 256) {
         const int l = e & 63, i = e >> 6;
         const int xo = l & 15, gg = l >> 4;
@@ -242,6 +251,7 @@ __global__ void __launch_bounds__(256, (FirFastCfg<UPL, KY, NCGL>::U <= 6 ? 4 : 
             const float t = (j >= 0 && j < p.kx) ? p.taps[i * p.kx + j] : 0.f;
             hi[j8] = (bf16)t;
             lo[j8] = (bf16)(t - (float)hi[j8]);
+            my_lo |= (float)lo[j8] != 0.f;
         }
         char* dst = toep + (i * 2) * 1024 + l * 16;
         *reinterpret_cast<bf16x8*>(dst) = hi;
@@ -250,18 +260,54 @@ __global__ void __launch_bounds__(256, (FirFastCfg<UPL, KY, NCGL>::U <= 6 ? 4 : 
 
     const int64_t t0 = p.ntiles * blockIdx.x / gridDim.x;
     const int64_t t1 = p.ntiles * (blockIdx.x + 1) / gridDim.x;
+    // taps that are exact in bf16 (the binomial kernels of Blur.make_kernel, nvidia_ops.py:73-78) have no low part: half the MFMAs
+    const bool need_lo = __syncthreads_or(my_lo) != 0;
+    // Walk: column-major inside (image, channel block) -- consecutive tiles are vertical neighbours and share halo rows
+    // (measured, not kept: the channel blocks of a column next to each other in the walk, or the block fastest: 15-25 %
+    // slower at 64 / 128 channels, a few % faster at 256 / 512).  The position is decoded once and then stepped: a
+    // decode per tile was a 64-bit and three 32-bit integer divisions, ~300 instructions, twice per tile.
+    struct Pos {
+        int n, cb, tx, ty;
+    };
     const int tiles_per_cb = p.tiles_x * p.tiles_y;
-    auto decode = [&](int64_t t, int& n, int& cb, int& oy0, int& ox0) {
-        // column-major walk inside (image, channel block): consecutive tiles are vertical neighbours and share halo rows
-        // (measured, not kept: the channel blocks of a column next to each other in the walk, or the block fastest --
-        // 15-25 % slower at 64 / 128 channels, a few % faster at 256 / 512)
-        const int64_t img = t / tiles_per_cb;
-        const int rem = (int)(t - img * tiles_per_cb);
-        n = (int)(img / p.ncb);
-        cb = (int)(img - (int64_t)n * p.ncb);
-        const int tx = rem / p.tiles_y;
-        oy0 = (rem - tx * p.tiles_y) * TH;
-        ox0 = tx * 32;
+    const bool ROWMAJOR = p.rowmajor != 0;
+    Pos cur;
+    {
+        const int64_t img = t0 / tiles_per_cb;
+        const int rem = (int)(t0 - img * tiles_per_cb);
+        cur.n = (int)(img / p.ncb);
+        cur.cb = (int)(img - (int64_t)cur.n * p.ncb);
+        if (ROWMAJOR) {
+            cur.ty = rem / p.tiles_x;
+            cur.tx = rem - cur.ty * p.tiles_x;
+        } else {
+            cur.tx = rem / p.tiles_y;
+            cur.ty = rem - cur.tx * p.tiles_y;
+        }
+    }
+    auto advance = [&](const Pos q) {
+        Pos r = q;
+        bool wrap;
+        if (ROWMAJOR) {
+            wrap = ++r.tx == p.tiles_x;
+            if (wrap) {
+                r.tx = 0;
+                wrap = ++r.ty == p.tiles_y;
+                if (wrap) r.ty = 0;
+            }
+        } else {
+            wrap = ++r.ty == p.tiles_y;
+            if (wrap) {
+                r.ty = 0;
+                wrap = ++r.tx == p.tiles_x;
+                if (wrap) r.tx = 0;
+            }
+        }
+        if (wrap && ++r.cb == p.ncb) {
+            r.cb = 0;
+            ++r.n;
+        }
+        return r;
     };
 
     // ---- this lane's chunks of the region, decoded once ------------------------------------------------
@@ -275,20 +321,27 @@ __global__ void __launch_bounds__(256, (FirFastCfg<UPL, KY, NCGL>::U <= 6 ? 4 : 
         const int idx = u * 256 + tid;
         const int p8 = idx >> SH, r8 = idx & ((1 << SH) - 1);
         const int c8 = r8 >> 3;
-        const int pix = p8 * 8 + (r8 & 7);
-        const int ry = pix / RWR, rxx = pix - ry * RWR;
-        ryx[u] = (pix < NPX && rxx < p.ncols) ? ((unsigned)ry << 16 | (unsigned)rxx) : 0xffffffffu;
+        const int pc = p8 * 8 + (r8 & 7);              // pixel of the compact (RH x NCOLS) grid
+        const int ry = pc / NCOLS, rxx = pc - ry * NCOLS;
+        ryx[u] = (pc < NPC && rxx < p.ncols) ? ((unsigned)ry << 16 | (unsigned)rxx) : 0xffffffffu;
         soff[u] = ((ry * p.W + rxx) * p.C + c8 * 8) * 2;
-        ldso[u] = pix < NPX ? (c8 >> 1) * PL + pix * 32 + (c8 & 1) * 16 : -1;
+        ldso[u] = pc < NPC ? (c8 >> 1) * PL + (ry * RWR + rxx) * 32 + (c8 & 1) * 16 : -1;
     }
-    v4u pre[U];
-    auto issue = [&](int n, int cb, int oy0, int ox0) {
+    // the columns no chunk ever writes: zero (they meet zero taps, and 0 x stale bits must not be a NaN)
+    for (int e = tid; e < ncg * RH * (RWR - NCOLS) * 2; e += 256) {
+        const int h = e & 1, pz = e >> 1;
+        const int gi = pz / (RH * (RWR - NCOLS)), r = pz - gi * (RH * (RWR - NCOLS));
+        const int ry = r / (RWR - NCOLS), rxx = NCOLS + r - ry * (RWR - NCOLS);
+        *reinterpret_cast<v4u*>(reg + gi * PL + (ry * RWR + rxx) * 32 + h * 16) = v4u{0u, 0u, 0u, 0u};
+    }
+    v4u pre[PD][U];
+    auto issue = [&](v4u (&pre)[U], int n, int cb, int oy0, int ox0) {
         const int iy0 = (oy0 - p.py1 + up - 1) >> UPL;
         const int ix0 = (ox0 - p.px1 + up - 1) >> UPL;
         const int iy1 = (oy0 + TH - 1 - p.py1 + KY - 1) >> UPL;
         // the window of region (row, column) that lies inside the image and inside this tile's rows: wave-uniform
         int rlo = iy0 < 0 ? -iy0 : 0, rhi = min(iy1 - iy0, p.H - 1 - iy0);
-        int xlo = ix0 < 0 ? -ix0 : 0, xhi = min(RWR - 1, p.W - 1 - ix0);
+        int xlo = ix0 < 0 ? -ix0 : 0, xhi = min(NCOLS - 1, p.W - 1 - ix0);
         if (rhi < rlo || xhi < xlo) { rlo = 0x7fff; rhi = 0x7fff; xlo = 0; xhi = 0; }
         const unsigned lo_u = (unsigned)rlo << 16 | (unsigned)xlo, rng_u = (unsigned)(rhi - rlo) << 16 | (unsigned)(xhi - xlo);
         const us2 lo_pk = __builtin_bit_cast(us2, lo_u), rng_pk = __builtin_bit_cast(us2, rng_u);
@@ -298,10 +351,14 @@ __global__ void __launch_bounds__(256, (FirFastCfg<UPL, KY, NCGL>::U <= 6 ? 4 : 
             const us2 d = __builtin_bit_cast(us2, ryx[u]) - lo_pk;  // wraps to a large value below the window
             const us2 m = __builtin_elementwise_max(d, rng_pk);
             const bool ok = __builtin_bit_cast(unsigned, m) == rng_u;
+#ifdef GAN_FIR_NOLOAD  // diagnostic build: no input traffic
+            pre[u] = __builtin_amdgcn_raw_buffer_load_b128(rx, ok && soff[u] == -12345 ? (unsigned)(base + soff[u]) : INV, 0, 0);
+#else
             pre[u] = __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? (unsigned)(base + soff[u]) : INV, 0, 0);
+#endif
         }
     };
-    auto commit = [&]() {
+    auto commit = [&](const v4u (&pre)[U]) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (u < C::FULL || ldso[u] >= 0) *reinterpret_cast<v4u*>(reg + ldso[u]) = pre[u];  // (cells outside the window get zeros)
@@ -315,22 +372,23 @@ __global__ void __launch_bounds__(256, (FirFastCfg<UPL, KY, NCGL>::U <= 6 ? 4 : 
     const int st_pix = NCGL >= 1 ? li : li + 16 * (g & 1);
     const int st_lane = (st_pix * p.C + (NCGL >= 1 ? 16 * (g & 1) : 0) + 8 * (g >> 1)) * 2;
     const unsigned img_bytes = (unsigned)(p.Ho * p.Wo * p.C * 2);
-    if (t0 < t1) {
-        int n, cb, oy0, ox0;
-        decode(t0, n, cb, oy0, ox0);
-        issue(n, cb, oy0, ox0);
+    // tiles t0 .. t0 + PD - 1 in flight before the first barrier; iteration t parks tile t's chunks, then issues tile t + PD
+    // into the register set it has just emptied
+    Pos ahead = cur;
+#pragma unroll
+    for (int d = 0; d < PD; ++d) {
+        if (t0 + d < t1) issue(pre[d], ahead.n, ahead.cb, ahead.ty * TH, ahead.tx * 32);
+        ahead = advance(ahead);
     }
-    for (int64_t t = t0; t < t1; ++t) {
-        int n, cb, oy0, ox0;
-        decode(t, n, cb, oy0, ox0);
+    auto iteration = [&](auto setc, const int64_t t) {
+        constexpr int SET = decltype(setc)::value;
+        const int n = cur.n, cb = cur.cb, oy0 = cur.ty * TH, ox0 = cur.tx * 32;
+        cur = advance(cur);
         __syncthreads();  // previous tile's fragment reads (and the tap matrices' stores) are done
-        commit();
+        commit(pre[SET]);
         __syncthreads();
-        if (t + 1 < t1) {
-            int n2, cb2, oy2, ox2;
-            decode(t + 1, n2, cb2, oy2, ox2);
-            issue(n2, cb2, oy2, ox2);
-        }
+        if (t + PD < t1) issue(pre[SET], ahead.n, ahead.cb, ahead.ty * TH, ahead.tx * 32);
+        ahead = advance(ahead);
         f32x4 acc[NF];
 #pragma unroll
         for (int f = 0; f < NF; ++f) acc[f] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -352,7 +410,7 @@ __global__ void __launch_bounds__(256, (FirFastCfg<UPL, KY, NCGL>::U <= 6 ? 4 : 
                     const int row = UPL == 0 ? fr + i : (fr + i + WPAR) >> 1;
                     const bf16x8 a = fir_tr_frag(reg + frag_base + cgi * PL + (row * RWR + fx * XSTEP) * 32);
                     acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bhi, acc[f], 0, 0, 0);
-                    acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, blo, acc[f], 0, 0, 0);
+                    if (need_lo) acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, blo, acc[f], 0, 0, 0);
                 }
             }
         };
@@ -395,8 +453,16 @@ __global__ void __launch_bounds__(256, (FirFastCfg<UPL, KY, NCGL>::U <= 6 ? 4 : 
                 xb[d] = sw[1];
             }
             const v4u o = {xa[0], xa[1], xb[0], xb[1]};
+#ifdef GAN_FIR_NOSTORE  // diagnostic build: no output traffic
+            __builtin_amdgcn_raw_buffer_store_b128(o, ry_, st_pix < wlim && o[0] == 0x12345678u ? (unsigned)st_lane : INV, sbase, 0);
+#else
             __builtin_amdgcn_raw_buffer_store_b128(o, ry_, st_pix < wlim ? (unsigned)st_lane : INV, sbase, 0);
+#endif
         }
+    };
+    for (int64_t t = t0; t < t1; t += PD) {
+        iteration(std::integral_constant<int, 0>{}, t);
+        if (PD == 2 && t + 1 < t1) iteration(std::integral_constant<int, PD - 1>{}, t + 1);
     }
 }
 
@@ -420,7 +486,7 @@ int gan_upfirdn2d_mfma(const void* x, const float* taps, void* y, int N, int H, 
     a.RWr = 32 * a.KC + a.xstep;
     a.ncols = a.xstep + kneed + 1;
     a.rw_magic = (unsigned)((0x100000000ULL + a.RWr - 1) / a.RWr);
-    const bool fast = (((uintptr_t)y) & 15) == 0 && down == 1 && a.KC == 1 && ky >= 2 && ky <= 4 && (int64_t)Ho * Wo * C * 2 < (1LL << 31) && !(getenv("GAN_AMD_FIR_OLD") && getenv("GAN_AMD_FIR_OLD")[0] == '1');
+    const bool fast = (((uintptr_t)y) & 15) == 0 && down == 1 && a.KC == 1 && ky >= 2 && ky <= 4 && kx <= ky && (int64_t)Ho * Wo * C * 2 < (1LL << 31) && !(getenv("GAN_AMD_FIR_OLD") && getenv("GAN_AMD_FIR_OLD")[0] == '1');
     int lds = 0;
     int ncg_log2 = 2;
     for (;; --ncg_log2) {
@@ -446,6 +512,12 @@ int gan_upfirdn2d_mfma(const void* x, const float* taps, void* y, int N, int H, 
     int64_t grid = 256LL * per_cu;
     if (grid > a.ntiles) grid = a.ntiles;
     a.x_bytes = (unsigned)((int64_t)N * H * W * C * 2);
+    {
+        // under 2x upsampling the output is 4x the input: rows of adjacent tiles written one after the other (3.3 -> 3.5 TB/s
+        // at 64 channels) matter more than the halo rows shared with the tile above (stride 1: row-major is 3-6 % slower)
+        const char* e = getenv("GAN_AMD_FIR_ROWMAJOR");
+        a.rowmajor = e ? atoi(e) : (up == 2 ? 1 : 0);
+    }
     if (fast) {
 #define FIR_FAST(UPL_, KY_, NCGL_)                                                                                          \
     do {                                                                                                                    \
