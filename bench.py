@@ -35,7 +35,7 @@ import torch.distributed as dist  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16
 # profile family (gan_amd/functional.py) -> device kernel; the first three are priced against the MFMA peak
-MFMA_FAMILIES = {"conv2d_fwd_wide_halo": "conv_wide_halo_k<...>", "conv2d_fwd_wide128": "conv_wide_k<128, 2>", "conv2d_fwd_wide64": "conv_wide_k<64, 2> / conv_wide_k<64, 4>",
+MFMA_FAMILIES = {"conv2d_fwd_wide_halo": "conv_wide_halo4_k<BN, UP2> (16-wide tiles) / conv_wide_halo_k<BN, 8, UP2> (8 x 8 maps)", "conv2d_fwd_wide128": "conv_wide_k<128, 2>", "conv2d_fwd_wide64": "conv_wide_k<64, 2> / conv_wide_k<64, 4>",
                  "conv2d_fwd": "conv_fwd_k<...>", "conv2d_wgrad": "conv_wgrad_tiled_k<...> / conv_wgrad_k<...>"}
 HBM_FAMILIES = {"conv2d_fwd_thin": "conv_thin_k<...>", "conv2d_wgrad_thin": "conv_thin_wgrad_k<...>"}
 
@@ -159,7 +159,7 @@ def pmc_traffic_leg(roof):
     import tempfile
 
     shapes = {  # family -> (tools/bench_op.py arguments, kernel-name fragment, algorithmic bytes of that launch)
-        "conv2d_fwd_wide_halo": (["fwd", "256", "128", "32", "32", "128", "3"], "conv_wide_halo_k<128", 2 * (256 * 32 * 32 * 128) * 2 + 128 * 1152 * 2),
+        "conv2d_fwd_wide_halo": (["fwd", "256", "128", "32", "32", "128", "3"], "conv_wide_halo4_k<128", 2 * (256 * 32 * 32 * 128) * 2 + 128 * 1152 * 2),
         "conv2d_fwd_wide128": (["fwd", "64", "128", "32", "32", "128", "3"], "conv_wide_k<128", 2 * (64 * 32 * 32 * 128) * 2 + 128 * 1152 * 2),
         "conv2d_fwd_wide64": (["fwd", "32", "512", "8", "8", "512", "3"], "conv_wide_k<64", 2 * (32 * 8 * 8 * 512) * 2 + 512 * 4608 * 2),
         "conv2d_wgrad": (["wgrad", "256", "128", "32", "32", "128", "3"], "conv_wgrad_tiled_k", 2 * (256 * 32 * 32 * 128) * 2 + 128 * 1152 * 4),

@@ -278,6 +278,7 @@ class Trainer:
         GF.prepack_weights(self._conv_w_g)
         GF.prepack_weights(self._conv_w_d)
         early_g = None  # (zs, generator output) of the G step when its forward ran under D's all-reduce
+        d_losses = []   # loss_d of every discriminator pass of the iteration (n_disc x grad_accum values)
         for i in range(cfg.n_disc):
             cached_reals: Optional[List[Tensor]] = [] if i == cfg.n_disc - 1 else None
             if cfg.method == "wgan" and cfg.regularizer == "none":
@@ -303,6 +304,7 @@ class Trainer:
                     self.red_d.prepare()
                 if a == 0 and not overlap:
                     self.red_d.arena.begin_direct()
+                d_losses.append(loss_d.detach())
                 with GF.direct_param_grads(not overlap):  # (the hook-driven exchange needs autograd's accumulation step)
                     loss_d.backward()
                 if last:
@@ -349,7 +351,8 @@ class Trainer:
         if overlap:
             self.red_g.zero_grad()
         # tensors, not floats: no host sync here (the reference syncs every 50 steps, train_celeba.py:153-160)
-        return {"loss/d": loss_d.detach(), "d/real": d_reals.detach().mean(), "d/fake": d_fakes.detach().mean(), "loss/g": loss_g.detach()}
+        return {"loss/d": loss_d.detach(), "d/real": d_reals.detach().mean(), "d/fake": d_fakes.detach().mean(), "loss/g": loss_g.detach(),
+                "loss/d_steps": torch.stack([t.float().reshape(()) for t in d_losses])}
 
 
 def synthetic_reals(cfg: TrainConfig, device: torch.device, local_batch: int, seed: int = 0, rank: int = 0, world: int = 1) -> Callable[[], Tensor]:

@@ -57,6 +57,12 @@ def det_state(shapes: Mapping[str, tuple], seed: int, *, bias_amp: float = 0.1, 
     return out
 
 
+def recipe_state(shapes: Mapping[str, tuple], seed: int, scale_amp: float, wgain: float) -> Dict[str, torch.Tensor]:
+    """det_state for the trainer-recipe fixtures (tests/golden/trainer_recipes.pt): biases +-0.05, matrices / kernels x wgain."""
+    sd = det_state({k: tuple(v) for k, v in shapes.items()}, seed=seed, bias_amp=0.05, scale_amp=scale_amp)
+    return {k: (v * wgain if v.ndim >= 2 else v) for k, v in sd.items()}
+
+
 def projections(t: torch.Tensor, salt: int = 7) -> torch.Tensor:
     """Compact fingerprint of a big tensor: [sum, abs-sum, <t, r1>, <t, r2>] in float64."""
     t64 = t.detach().double().flatten().cpu()

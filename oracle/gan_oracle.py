@@ -557,6 +557,7 @@ def train_iteration(
     discriminator frozen.  Random draws follow the reference's call order: z, [noise...], [alpha]."""
     reg_fn = regularizer(reg)
     disc = lambda imgs: disc_fn(d_sd, imgs)  # noqa: E731
+    d_losses = []
     for i in range(n_disc):
         if method == "wgan" and reg == "none":
             with torch.no_grad():
@@ -576,6 +577,7 @@ def train_iteration(
         loss_d.backward()
         optim_d.step()
         optim_d.zero_grad()
+        d_losses.append(float(loss_d.detach()))
 
     for p in d_sd.values():
         p.requires_grad_(False)
@@ -591,4 +593,5 @@ def train_iteration(
         "loss_g": float(loss_g.detach()),
         "d_real": float(d_reals.detach().mean()),
         "d_fake": float(d_fakes.detach().mean()),
+        "loss_d_all": d_losses,
     }

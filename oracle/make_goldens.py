@@ -37,7 +37,7 @@ from modelling import stylegan as ref_sg  # noqa: E402
 from modelling import stylegan2 as ref_sg2  # noqa: E402
 
 from oracle import gan_oracle as O  # noqa: E402
-from oracle.detparams import det_state, det_uniform, projections  # noqa: E402
+from oracle.detparams import det_state, det_uniform, projections, recipe_state  # noqa: E402
 from oracle.tape import RandTape  # noqa: E402
 
 OUT = os.path.join(REPO, "tests", "golden")
@@ -412,6 +412,94 @@ def gold_trajectory():
     )
 
 
+def _ref_train_iteration(gen, disc, optim_g, optim_d, ema, criterion, regularizer, next_reals, n_disc, z_dim, clip):
+    """One `while` body of train_celeba.py:111-149 with grad_accum = 1, restated from the reference by reading (the
+    script itself needs wandb / torchvision / a CelebA download), on the reference's modules, losses and EMA."""
+    d_losses, cached = [], None
+    for i in range(n_disc):
+        if clip:  # train_celeba.py:115-118
+            with torch.no_grad():
+                for p in disc.parameters():
+                    p.clip_(-0.01, 0.01)
+        reals = next_reals()
+        if i == n_disc - 1:
+            cached = reals.clone()
+        reals.requires_grad_()
+        zs = torch.randn(reals.shape[0], z_dim)
+        with torch.no_grad():
+            fakes = gen(zs)
+        d_reals = disc(reals)
+        d_fakes = disc(fakes)
+        loss_d = criterion.d_loss(d_reals, d_fakes)
+        if regularizer is not None:
+            loss_d = loss_d + regularizer(disc, reals, fakes, d_reals)
+        loss_d.backward()
+        optim_d.step()
+        optim_d.zero_grad()
+        d_losses.append(float(loss_d))
+    disc.requires_grad_(False)
+    zs = torch.randn(reals.shape[0], z_dim)
+    loss_g = criterion.g_loss(disc(gen(zs)), lambda: disc(cached))
+    loss_g.backward()
+    optim_g.step()
+    optim_g.zero_grad()
+    disc.requires_grad_(True)
+    ema.step()
+    return d_losses, float(loss_g)
+
+
+def gold_trainer_recipes():
+    """The train loop on the README recipes the 16 x 16 trajectory does not reach (README.md:55,60):
+      dcgan_wgan_gp  DCGAN, WGAN + gradient penalty, n_disc = 5, Adam(1e-4, (0, 0.9)), 64 x 64, batch 8, 3 iterations
+      dcgan_wgan_clip  DCGAN, WGAN with weight clipping (no regularizer: train_celeba.py:115-118), n_disc = 2, 2 iterations
+      stylegan2_64   StyleGAN2 64 x 64, base_dim 64 both networks, hinge + R1, Adam(2e-4, (0, 0.9)), batch 8, 1 iteration
+    Deterministic parameters (oracle.detparams: only shape tables and seeds are stored), deterministic reals, the random
+    draws recorded; per iteration every D loss and the G loss, at the end a fingerprint of every parameter."""
+    out = {}
+    # (wgain: the DCGAN nets get a quarter of det_state's kaiming-variance weights -- at full width the WGAN losses grow
+    # 5x per iteration and the third iteration amplifies fp32 rounding past 1e-4; the reference's own init is N(0, 0.02))
+    for name, model, size, kw_g, kw_d, method, reg, n_disc, lr, iters, batch, wgain in (
+        ("dcgan_wgan_gp", "dcgan", 64, {}, {"norm": "none"}, "wgan", "wgan-gp", 5, 1e-4, 3, 8, 0.25),
+        ("dcgan_wgan_clip", "dcgan", 64, {}, {"norm": "none"}, "wgan", "none", 2, 1e-4, 2, 8, 0.25),
+        ("stylegan2_64", "stylegan2", 64, {"base_dim": 64}, {"base_dim": 64}, "hinge", "r1", 1, 2e-4, 1, 8, 1.0),
+    ):
+        gen = build_generator(model, img_size=size, **kw_g)
+        disc = out_of_place(build_discriminator(model, img_size=size, **kw_d))
+        g_shapes = {k: tuple(v.shape) for k, v in gen.state_dict().items()}
+        d_shapes = {k: tuple(v.shape) for k, v in disc.state_dict().items()}
+        gseed, dseed = 21, 22
+        gen.load_state_dict(recipe_state(g_shapes, gseed, 0.05, wgain))
+        disc.load_state_dict(recipe_state(d_shapes, dseed, 0.5, wgain))
+        ema = ref_utils.EMA(gen, warmup=2)
+        optim_d = torch.optim.Adam(disc.parameters(), lr, betas=(0.0, 0.9))
+        optim_g = torch.optim.Adam(gen.parameters(), lr, betas=(0.0, 0.9))
+        criterion = ref_losses.get_loss(method)
+        regularizer = ref_losses.get_regularizer(reg)
+        salt = [5000]
+
+        def next_reals():
+            salt[0] += 1
+            return det_uniform((batch, 3, size, size), salt[0]) * 2.0
+
+        steps, tapes = [], []
+        for _ in range(iters):
+            with RandTape() as tape:
+                d_losses, g_loss = _ref_train_iteration(gen, disc, optim_g, optim_d, ema, criterion, regularizer, next_reals, n_disc, 128,
+                                                        clip=(method == "wgan" and reg == "none"))
+            tapes.append(tape.tape)
+            steps.append(d_losses + [g_loss])
+        out[name] = {
+            "model": model, "img_size": size, "gen_kwargs": kw_g, "disc_kwargs": kw_d, "method": method, "regularizer": reg, "n_disc": n_disc,
+            "lr": lr, "batch": batch, "wgain": wgain, "gen_seed": gseed, "disc_seed": dseed, "gen_shapes": {k: list(v) for k, v in g_shapes.items()},
+            "disc_shapes": {k: list(v) for k, v in d_shapes.items()}, "reals_salt0": 5000, "ema_warmup": 2, "tape": tapes,
+            "steps": torch.tensor(steps, dtype=torch.float64),
+            "final": {"gen": {k: projections(v) for k, v in gen.state_dict().items()}, "disc": {k: projections(v) for k, v in disc.state_dict().items()},
+                      "ema": {k: projections(v) for k, v in ema.ema_model.state_dict().items()}},
+        }
+        print(name, steps)
+    save("trainer_recipes", out)
+
+
 def gold_generators_v1():
     """StyleGanGenerator and ProgressiveGanGenerator (stylegan.py:50-85, progressive_gan.py:103-133) at 16x16, base_dim 16:
     deterministic parameters (oracle.detparams, only the shape table is stored), recorded noise, image, loss and every
@@ -514,3 +602,4 @@ if __name__ == "__main__":
     gold_resample_convs()
     gold_generators_v1()
     gold_diff_augment()
+    gold_trainer_recipes()

@@ -331,6 +331,149 @@ def test_trajectory16_golden(dev, golden):
             assert abs(float(got[1] - ref[1])) < 2e-2 * max(float(ref[1]), 1e-3), k
 
 
+def _recipe_trainer(dev, g, **over):
+    from gan_amd.train_celeba import TrainConfig, Trainer
+    from oracle.detparams import recipe_state
+
+    kw = dict(model=g["model"], img_size=g["img_size"], gen_kwargs=dict(g["gen_kwargs"]), disc_kwargs=dict(g["disc_kwargs"]), method=g["method"],
+              regularizer=g["regularizer"], n_disc=g["n_disc"], batch_size=g["batch"], optimizer="Adam", optimizer_kwargs={"betas": [0, 0.9]},
+              lr=g["lr"], device="cuda", mixed_precision=False, channels_last=False)
+    kw.update(over)
+    tr = Trainer(TrainConfig(**kw), dev)
+    g_state = recipe_state(g["gen_shapes"], g["gen_seed"], 0.05, g["wgain"])
+    tr.gen.load_state_dict(g_state)
+    tr.disc.load_state_dict(recipe_state(g["disc_shapes"], g["disc_seed"], 0.5, g["wgain"]))
+    tr.gen_ema.ema_model.load_state_dict(g_state)
+    tr.gen_ema.warmup = g["ema_warmup"]
+    return tr
+
+
+@pytest.mark.parametrize("name", ["dcgan_wgan_gp", "dcgan_wgan_clip", "stylegan2_64"])
+def test_trainer_recipes_golden(dev, golden, name):
+    """The Trainer on the README recipes the 16 x 16 trajectory does not reach, against the REFERENCE's own modules run
+    through the train_celeba.py:111-149 loop (oracle/make_goldens.py: gold_trainer_recipes): DCGAN WGAN-GP with n_disc = 5
+    (five gradient-penalty double backwards per iteration), DCGAN WGAN with weight clipping (:115-118), StyleGAN2 at
+    64 x 64 / base_dim 64 with hinge + R1 (README.md:55,60).  Every D loss and the G loss of every iteration with the
+    reference's recorded draws, then a fingerprint of every parameter (fp32, launched from the host)."""
+    from oracle.detparams import det_uniform, projections
+    from oracle.tape import RandTape
+
+    g = golden("trainer_recipes")[name]
+    tr = _recipe_trainer(dev, g)
+    salt = [g["reals_salt0"]]
+
+    def next_reals():
+        salt[0] += 1
+        return (det_uniform((g["batch"], 3, g["img_size"], g["img_size"]), salt[0]) * 2.0).to(dev)
+
+    for step, ref in enumerate(g["steps"]):
+        with RandTape(g["tape"][step]):
+            logs = tr.train_step(next_reals)
+        got = [float(v) for v in logs["loss/d_steps"]] + [float(logs["loss/g"])]
+        assert len(got) == len(ref)
+        # a WGAN loss is a difference of terms of size `scale`, and the trajectory amplifies a rounding difference about
+        # 4x per iteration (n_disc Adam steps with beta1 = 0 are sign-like updates): the CPU oracle, fp32 like the
+        # reference, sits 9e-5 from it at the third iteration, the MFMA path (other summation order) 2.6e-3
+        grow = 4.0 ** step
+        scale = max(1.0, float(ref.abs().max())) * grow
+        for j, (a, b) in enumerate(zip(got, ref.tolist())):
+            assert math.isclose(a, b, rel_tol=2e-4 * grow, abs_tol=2e-5 * scale), (name, step, j, a, b)
+    for mod, key in ((tr.gen, "gen"), (tr.disc, "disc"), (tr.gen_ema.ema_model, "ema")):
+        sd = mod.state_dict()
+        for k, ref in g["final"][key].items():
+            if not torch.is_floating_point(sd[k]):
+                continue
+            got = projections(sd[k])
+            assert float((got - ref).abs().max()) < 5e-4 * 4.0 ** (len(g["steps"]) - 1) * max(float(ref[1]), 1e-3), (name, key, k, got, ref)
+
+
+def test_trainer_graph_matches_host_launches_n_disc_and_grad_accum(dev, golden):
+    """The iteration replayed as HIP graphs against the same iteration launched from the host, where a step has several
+    discriminator passes: n_disc = 2 (a blocking gradient cut inside the captured iteration) and grad_accum = 2 (the
+    gradient arena keeps accumulating across two backward passes before the exchange).  DCGAN WGAN-GP; same seed, so the
+    device generator hands both trainers the same draws; five iterations (two of them before the capture), four with Adam.
+    SGD: the update is proportional to the gradient, so everything agrees to rounding.  Adam with beta1 = 0 turns the
+    rounding-sized gradient components behind the generator's BatchNorm (the direction that rescales a channel has zero
+    gradient) into lr-sized steps: there both networks' parameters are held to the size of a step and the losses to 5e-3 instead (two host-launched runs differ by as much: the
+    split-K reductions add in arrival order, and the fifth iteration is 16x further apart than the fourth)."""
+    g = golden("trainer_recipes")["dcgan_wgan_gp"]
+    for over in (dict(n_disc=2), dict(n_disc=1, grad_accum=2), dict(n_disc=2, optimizer="SGD", optimizer_kwargs={}, lr=1e-3),
+                 dict(n_disc=1, grad_accum=2, optimizer="SGD", optimizer_kwargs={}, lr=1e-3)):
+        runs = []
+        for graph in (False, True):
+            torch.manual_seed(77)
+            tr = _recipe_trainer(dev, g, hip_graph=graph, graph_warmup=2, **over)
+            micro = g["batch"] // over.get("grad_accum", 1)
+            reals = [torch.randn(micro, 3, g["img_size"], g["img_size"], device=dev) for _ in range(4)]
+            it = [0]
+
+            def next_reals():
+                it[0] += 1
+                return reals[it[0] % 4].clone()
+
+            losses = []
+            for _ in range(5 if over.get("optimizer") == "SGD" else 4):
+                logs = tr.train_step(next_reals)
+                losses.append([float(v) for v in logs["loss/d_steps"]] + [float(logs["loss/g"])])
+            if graph:
+                assert tr._graph is not None
+                cuts = [cut[0] for _, cut in tr._graph if cut is not None]
+                assert cuts == (["reduce", "start", "wait", "reduce"] if over["n_disc"] == 2 else ["reduce", "reduce"]), cuts
+            runs.append((losses, {k: v.detach().clone() for k, v in tr.disc.state_dict().items()}, {k: v.detach().clone() for k, v in tr.gen.state_dict().items()}))
+        (l0, d0, g0), (l1, d1, g1) = runs
+        for a, b in zip(l0, l1):
+            assert len(a) == over["n_disc"] * over.get("grad_accum", 1) + 1
+            tol = 1e-4 if over.get("optimizer") == "SGD" else 5e-3
+            for x, y in zip(a, b):
+                assert math.isclose(x, y, rel_tol=tol, abs_tol=tol), (over, l0, l1)
+        for s0, s1 in ((d0, d1), (g0, g1)):
+            for k in s0:
+                if not torch.is_floating_point(s0[k]):
+                    continue
+                if over.get("optimizer") == "SGD":
+                    assert rel_err(s1[k], s0[k]) < 1e-4, (over, k)
+                else:
+                    diff = (s1[k] - s0[k]).abs()  # (a flipped sign moves an element by 2 lr per optimizer step; few flip)
+                    assert float(diff.max()) < 16 * g["lr"] and float(diff.mean()) < g["lr"], (over, k)
+
+
+def test_trainer_grad_accum_accumulates(dev, golden):
+    """grad_accum = 2 (train_celeba.py:120-135): the two backward passes of a discriminator step ADD their gradients (each
+    loss is the mean over its own micro-batch -- the reference does not rescale) before one optimizer step.  With SGD the
+    parameter change is -lr x that sum: compared with the two gradients computed one by one through the same modules."""
+    from gan_amd.losses import get_loss, get_regularizer
+    from oracle.tape import RandTape
+
+    g = golden("trainer_recipes")["dcgan_wgan_gp"]
+    torch.manual_seed(78)
+    tr = _recipe_trainer(dev, g, grad_accum=2, optimizer="SGD", optimizer_kwargs={}, lr=0.5, n_disc=1)  # (a step well above fp32 spacing)
+    micro = g["batch"] // 2
+    batches = [torch.randn(micro, 3, 64, 64, device=dev) for _ in range(2)]
+    before = {k: v.detach().clone() for k, v in tr.disc.named_parameters()}
+    # the expected gradient sum, pass by pass, with the draws recorded for the trainer to replay
+    crit, reg = get_loss("wgan"), get_regularizer("wgan-gp")
+    expect = {k: torch.zeros_like(v) for k, v in before.items()}
+    with RandTape() as rec:
+        for reals in batches:
+            reals = reals.clone().requires_grad_()
+            zs = torch.randn(micro, 128, device=dev)
+            with torch.no_grad():
+                fakes = tr.gen(zs)
+            d_reals, d_fakes = tr.disc(reals), tr.disc(fakes)
+            loss = crit.d_loss(d_reals, d_fakes) + reg(tr.disc, reals, fakes, d_reals)
+            grads = torch.autograd.grad(loss, list(tr.disc.parameters()))
+            for (k, _), gr in zip(tr.disc.named_parameters(), grads):
+                expect[k] += gr
+        for _ in range(2):  # the generator step's draws
+            torch.randn(micro, 128, device=dev)
+    feed = iter(batches)
+    with RandTape(rec.tape):
+        tr.train_step(lambda: next(feed).clone())
+    for k, p in tr.disc.named_parameters():
+        upd = p.detach() - before[k]
+        assert rel_err(upd, -0.5 * expect[k]) < 1e-4, (k, rel_err(upd, -0.5 * expect[k]))
+
+
 def _sync(module, sd):
     with torch.no_grad():
         for k, v in module.state_dict().items():

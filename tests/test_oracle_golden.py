@@ -8,7 +8,7 @@ import torch
 
 from conftest import rel_err
 from oracle import gan_oracle as O
-from oracle.detparams import det_state, det_uniform, projections
+from oracle.detparams import det_state, det_uniform, projections, recipe_state
 from oracle.tape import RandTape
 
 TOL = 1e-5
@@ -263,6 +263,42 @@ def test_trajectory16(golden):
     for (k, ref), e in zip(g["final"]["ema"].items(), ema):
         got = projections(e)
         assert float((got - ref).abs().max()) < 1e-4 * max(float(ref[1]), 1e-3), k
+
+
+def _recipe_fns(model):
+    return (O.dcgan_generator, O.dcgan_discriminator) if model == "dcgan" else (O.generator, O.discriminator)
+
+
+def test_trainer_recipes(golden):
+    """The oracle's train iteration on the README recipes (DCGAN WGAN-GP with n_disc = 5, DCGAN WGAN with weight clipping,
+    StyleGAN2 64 x 64 / base_dim 64 hinge + R1) against the losses and final parameters of the REFERENCE's modules run
+    through the train_celeba.py:111-149 loop (oracle/make_goldens.py: gold_trainer_recipes)."""
+    for name, g in golden("trainer_recipes").items():
+        gen_fn, disc_fn = _recipe_fns(g["model"])
+        g_sd = leaves_of(recipe_state(g["gen_shapes"], g["gen_seed"], 0.05, g["wgain"]))
+        d_sd = leaves_of(recipe_state(g["disc_shapes"], g["disc_seed"], 0.5, g["wgain"]))
+        opt_d = torch.optim.Adam(list(d_sd.values()), g["lr"], betas=(0.0, 0.9))
+        opt_g = torch.optim.Adam(list(g_sd.values()), g["lr"], betas=(0.0, 0.9))
+        salt = [g["reals_salt0"]]
+
+        def next_reals():
+            salt[0] += 1
+            return det_uniform((g["batch"], 3, g["img_size"], g["img_size"]), salt[0]) * 2.0
+
+        for step, ref in enumerate(g["steps"]):
+            with RandTape(g["tape"][step]):
+                logs = O.train_iteration(g_sd, d_sd, opt_g, opt_d, next_reals, method=g["method"], reg=g["regularizer"], n_disc=g["n_disc"],
+                                         gen_fn=gen_fn, disc_fn=disc_fn)
+            got = logs["loss_d_all"] + [logs["loss_g"]]
+            scale = max(1.0, float(ref.abs().max()))  # (a WGAN loss is a difference of terms of this size)
+            for j, (a, b) in enumerate(zip(got, ref.tolist())):
+                assert math.isclose(a, b, rel_tol=2e-4, abs_tol=2e-5 * scale), (name, step, j, a, b)
+        for sd, key in ((g_sd, "gen"), (d_sd, "disc")):
+            for k, ref in g["final"][key].items():
+                if not torch.is_floating_point(sd[k]) if k in sd else True:
+                    continue
+                got = projections(sd[k])
+                assert float((got - ref).abs().max()) < 2e-4 * max(float(ref[1]), 1e-3), (name, key, k)
 
 
 def test_resample_convs(golden):
