@@ -406,6 +406,7 @@ def main():
     next_reals = synthetic_reals(cfg, device, micro, seed=0, rank=rank, world=world)
 
     def sync():
+        trainer.flush()  # (multi-rank graph runs leave the generator's update pending across iterations: K steps = K updates)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()

@@ -59,6 +59,10 @@ class TrainConfig:
     # all Noise draws of a generator pass from one torch.randn launch (the same distribution, another walk through the
     # random stream than the reference's one draw per layer, stylegan.py:26)
     bulk_noise: bool = False
+    # HIP-graph path: leave the generator's gradient all-reduce in flight at the end of an iteration and apply its
+    # optimizer step + EMA update early in the next one, under work that does not read the generator (Trainer.flush()
+    # settles it).  On whenever the job has more than one rank; this switch turns it on for a single rank too (tests).
+    defer_g_step: bool = False
 
 
 def _fix_betas(kwargs: dict) -> dict:
@@ -98,6 +102,10 @@ class Trainer:
         self._graph = None
         self._graph_reals: List[Tensor] = []
         self._graph_logs: Optional[Dict[str, Tensor]] = None
+        self._defer_g = bool(cfg.hip_graph and (world > 1 or cfg.defer_g_step))
+        self._pending_g = False  # the generator's averaged gradients wait for their optimizer step (see flush)
+        self._inflight = None
+        self._inflight_g = None
         # train_celeba.py:75-77: any torch.optim class by name; Adam / AdamW run as one kernel over the flat arenas
         self.optim_d = make_optimizer(cfg.optimizer, self.disc, cfg.lr, okw, capturable=cfg.hip_graph)
         self.optim_g = make_optimizer(cfg.optimizer, self.gen, cfg.lr, okw, capturable=cfg.hip_graph)
@@ -110,10 +118,12 @@ class Trainer:
     def state_dict(self) -> Dict:
         """Everything a resumed run needs: both networks, the EMA copy with its step counter (utils.py:80), both optimizers,
         the iteration count.  Tensors and plain numbers only: loads with torch.load(weights_only=True)."""
+        self.flush()
         return {"step": self.step, "gen": self.gen.state_dict(), "disc": self.disc.state_dict(), "gen_ema": self.gen_ema.state_dict(),
                 "optim_g": self.optim_g.state_dict(), "optim_d": self.optim_d.state_dict()}
 
     def load_state_dict(self, state: Dict) -> None:
+        self._pending_g, self._inflight_g = False, None  # (a pending update belongs to the state being replaced)
         self.gen.load_state_dict(state["gen"])
         self.disc.load_state_dict(state["disc"])
         self.gen_ema.load_state_dict(state["gen_ema"])
@@ -150,12 +160,30 @@ class Trainer:
             logs = self._graph_step(next_reals)
         else:
             logs = self._run_eager(next_reals)
-        self.gen_ema.step()
+        if not self._pending_g:  # (deferred: the EMA update follows the generator's optimizer step, in _finish_g)
+            self.gen_ema.step()
         self.step += 1
         return logs
 
+    def flush(self) -> None:
+        """Settle a deferred generator update (cfg.defer_g_step / multi-rank HIP-graph runs): wait for the gradient
+        all-reduce left in flight by the last train_step, apply the optimizer step and the EMA update.  A no-op otherwise.
+        Called by state_dict(); call it before reading `gen` / `gen_ema` directly (sampling, evaluation, end of training)."""
+        self._finish_g()
+
+    def _finish_g(self) -> None:
+        if not self._pending_g:
+            return
+        work, self._inflight_g = self._inflight_g, None
+        if work is not None:
+            work.wait()  # orders the current stream behind the collective; the host does not block
+        self.optim_g.step()
+        self.gen_ema.step()
+        self._pending_g = False
+
     # ---- eager: gradient buckets are all-reduced from hooks while the backward pass is still running ----
     def _run_eager(self, next_reals: Callable[[], Tensor]) -> Dict[str, Tensor]:
+        self._finish_g()
         if self._graph is not None:  # after graph replays the arenas still hold the last gathered gradients
             self.red_d.zero_grad()
             self.red_g.zero_grad()
@@ -181,9 +209,16 @@ class Trainer:
         elif action == "start":
             self._inflight = self._flat_allreduce(red, async_op=True)
         elif action == "wait":
-            work, self._inflight = getattr(self, "_inflight", None), None
+            work, self._inflight = self._inflight, None
             if work is not None:
                 work.wait()  # orders the current stream behind the collective; the host does not block
+        elif action == "start_g":
+            self._inflight_g = self._flat_allreduce(red, async_op=True)
+            self._pending_g = True
+        elif action == "finish_g":
+            self._finish_g()
+        else:
+            raise ValueError(f"unknown gradient exchange {action!r}")
 
     # ---- HIP graphs ---------------------------------------------------------------------------------
     def _graph_step(self, next_reals: Callable[[], Tensor]) -> Dict[str, Tensor]:
@@ -199,7 +234,7 @@ class Trainer:
             GF.drop_packed()  # every packed weight the graphs read must be packed inside them
             feed = iter(self._graph_reals)
             # `.detach()`: an alias, so that requires_grad_ stays off the static buffer
-            it = self._iteration(lambda: next(feed).detach(), overlap=False)
+            it = self._iteration(lambda: next(feed).detach(), overlap=False, defer_g=self._defer_g)
             segments = []  # (graph, (action, reducer) of the gradient exchange that follows it | None)
             pool = torch.cuda.graph_pool_handle()
             torch.cuda.synchronize()
@@ -222,6 +257,12 @@ class Trainer:
                             self._graph_logs = stop.value
                             done = True
                     segments.append((graph, cut))
+                    if cut is not None and cut[0] == "start_g":  # the deferred iteration ends on this cut: collect its logs
+                        try:
+                            next(it)
+                        except StopIteration as stop:
+                            self._graph_logs = stop.value
+                        done = True
             except Exception as exc:  # capture refused (driver / allocator state): keep training, launched from the host
                 failed = exc
                 it.close()
@@ -237,6 +278,7 @@ class Trainer:
 
                 print(f"gan_amd: HIP graph capture failed ({type(failed).__name__}: {failed}); continuing without graphs", file=sys.stderr)
                 self.cfg.hip_graph = False
+                self._defer_g = False
                 self.disc.requires_grad_(True)
                 # what the aborted capture left behind was recorded, never executed: packed weights and padded inputs
                 # that point at graph-pool buffers, gradient tensors handed over by a backward pass that did not run
@@ -259,42 +301,70 @@ class Trainer:
         GF.drop_packed()  # a replay updates the weights without bumping their Python-side versions
         return {k: v.clone() for k, v in self._graph_logs.items()}
 
-    def _iteration(self, next_reals: Callable[[], Tensor], overlap: bool):
+    def _iteration(self, next_reals: Callable[[], Tensor], overlap: bool, defer_g: bool = False):
         """The iteration as a generator.  overlap=True (host-launched): gradient buckets are all-reduced from hooks
         while the backward pass runs, nothing is yielded.  overlap=False (HIP graphs): it yields (action, reducer) at
         the points where gradients cross ranks -- the cuts between the graphs:
-            ("start", red_d)  after the discriminator's backward: its arena's all-reduce is launched asynchronously
-            ("wait", red_d)   after the generator's FORWARD of the G step, which does not depend on D and so runs
-                              under that collective (same random draws in the same order: only stream order moves)
-            ("reduce", red)   a plain blocking exchange (generator gradients; D with n_disc > 1 or grad_accum > 1).
+            ("start", red_d)    after the last backward of a discriminator step: its arena's all-reduce is launched
+                                asynchronously
+            ("wait", red_d)     after the generator forward the NEXT pass needs -- the next discriminator step's fakes,
+                                or the G step's own forward -- which does not depend on D and so runs under that
+                                collective (same random draws in the same order: only stream order moves)
+            ("reduce", red_g)   the generator's exchange as a plain blocking all-reduce (defer_g = False), or
+            ("start_g", red_g)  launched asynchronously at the very end of the iteration, the optimizer step and the EMA
+                                update left pending (defer_g = True), until
+            ("finish_g", red_g) of the next iteration: placed after its first discriminator forward on the reals, the
+                                one piece of the coming iteration that does not read the generator.
         Why not buckets under the backward here too: with R1 every D parameter's gradient has a first-order part
         (produced head -> input) and a second-order part (produced input -> head), so no bucket is complete until
         the backward is nearly over; and G's large tensors (512-channel blocks) are the LAST its backward reaches.
         Returns the log dict."""
         cfg, disc, gen = self.cfg, self.disc, self.gen
-        # every GEMM image of both networks' conv weights in one launch each (the generator's changed at the end of
-        # the last iteration; the discriminator's are current unless the caches were dropped, as before a capture --
-        # so a replayed iteration starts by packing what it reads, whoever changed the weights)
-        GF.prepack_weights(self._conv_w_g)
-        GF.prepack_weights(self._conv_w_d)
-        early_g = None  # (zs, generator output) of the G step when its forward ran under D's all-reduce
-        d_losses = []   # loss_d of every discriminator pass of the iteration (n_disc x grad_accum values)
-        for i in range(cfg.n_disc):
-            cached_reals: Optional[List[Tensor]] = [] if i == cfg.n_disc - 1 else None
+
+        def clip_d():  # train_celeba.py:115-118
             if cfg.method == "wgan" and cfg.regularizer == "none":
                 with torch.no_grad():
                     for p in disc.parameters():
                         p.clip_(-0.01, 0.01)
+
+        # every GEMM image of both networks' conv weights in one launch each (the generator's changed at the end of
+        # the last iteration; the discriminator's are current unless the caches were dropped, as before a capture --
+        # so a replayed iteration starts by packing what it reads, whoever changed the weights)
+        GF.prepack_weights(self._conv_w_d)
+        hoisted = None  # (reals, D(reals)) of the first discriminator pass, run ahead of the generator's pending update
+        if defer_g and not overlap:
+            clip_d()
+            reals = next_reals()
+            reals.requires_grad_()
+            with self.autocast_ctx():
+                hoisted = (reals, disc(reals))
+            yield ("finish_g", self.red_g)
+        GF.prepack_weights(self._conv_w_g)
+        early = None    # (zs, fakes) of the coming discriminator step, computed under the previous step's all-reduce
+        early_g = None  # generator output of the G step's first pass, computed under the last D step's all-reduce
+        d_losses = []   # loss_d of every discriminator pass of the iteration (n_disc x grad_accum values)
+        for i in range(cfg.n_disc):
+            cached_reals: Optional[List[Tensor]] = [] if i == cfg.n_disc - 1 else None
+            if hoisted is None:
+                clip_d()
             for a in range(cfg.grad_accum):
-                reals = next_reals()
+                d_reals = None
+                if hoisted is not None:
+                    (reals, d_reals), hoisted = hoisted, None
+                else:
+                    reals = next_reals()
+                    reals.requires_grad_()
                 if cached_reals is not None:
                     cached_reals.append(reals.detach())  # an alias (only the relativistic loss reads it back)
-                reals.requires_grad_()
-                zs = torch.randn(reals.shape[0], self.z_dim, device=self.device)
-                with self.autocast_ctx():
-                    with torch.no_grad():
+                if early is not None:
+                    (zs, fakes), early = early, None
+                else:
+                    zs = torch.randn(reals.shape[0], self.z_dim, device=self.device)
+                    with self.autocast_ctx(), torch.no_grad():
                         fakes = gen(zs)
-                    d_reals = disc(reals)
+                with self.autocast_ctx():
+                    if d_reals is None:
+                        d_reals = disc(reals)
                     d_fakes = disc(fakes)
                     loss_d = self.criterion.d_loss(d_reals, d_fakes)
                     if self.regularizer is not None:
@@ -312,14 +382,15 @@ class Trainer:
                         self.red_d.finish()
                     else:
                         self.red_d.arena.gather_grads()
-                        if i == cfg.n_disc - 1 and cfg.grad_accum == 1:
-                            yield ("start", self.red_d)
-                            zs = torch.randn(reals.shape[0], self.z_dim, device=self.device)
-                            with self.autocast_ctx():
+                        yield ("start", self.red_d)
+                        zs = torch.randn(reals.shape[0], self.z_dim, device=self.device)
+                        with self.autocast_ctx():
+                            if i == cfg.n_disc - 1:
                                 early_g = gen(zs)
-                            yield ("wait", self.red_d)
-                        else:
-                            yield ("reduce", self.red_d)
+                            else:
+                                with torch.no_grad():
+                                    early = (zs, gen(zs))
+                        yield ("wait", self.red_d)
             self.optim_d.step()
             GF.prepack_weights(self._conv_w_d)
             if overlap:
@@ -331,7 +402,10 @@ class Trainer:
                 if early_g is None:
                     zs = torch.randn(reals.shape[0], self.z_dim, device=self.device)
                 with self.autocast_ctx():
-                    g_out = gen(zs) if early_g is None else early_g
+                    if early_g is None:
+                        g_out = gen(zs)
+                    else:
+                        g_out, early_g = early_g, None
                     loss_g = self.criterion.g_loss(disc(g_out), lambda: disc(cached_reals[a]))
                 last = a == cfg.grad_accum - 1
                 if last and overlap:
@@ -344,15 +418,19 @@ class Trainer:
                     self.red_g.finish()
         finally:
             disc.requires_grad_(True)
+        # tensors, not floats: no host sync here (the reference syncs every 50 steps, train_celeba.py:153-160)
+        logs = {"loss/d": loss_d.detach(), "d/real": d_reals.detach().mean(), "d/fake": d_fakes.detach().mean(), "loss/g": loss_g.detach(),
+                "loss/d_steps": torch.stack([t.float().reshape(()) for t in d_losses])}
         if not overlap:
             self.red_g.arena.gather_grads()
+            if defer_g:
+                yield ("start_g", self.red_g)
+                return logs
             yield ("reduce", self.red_g)
         self.optim_g.step()
         if overlap:
             self.red_g.zero_grad()
-        # tensors, not floats: no host sync here (the reference syncs every 50 steps, train_celeba.py:153-160)
-        return {"loss/d": loss_d.detach(), "d/real": d_reals.detach().mean(), "d/fake": d_fakes.detach().mean(), "loss/g": loss_g.detach(),
-                "loss/d_steps": torch.stack([t.float().reshape(()) for t in d_losses])}
+        return logs
 
 
 def synthetic_reals(cfg: TrainConfig, device: torch.device, local_batch: int, seed: int = 0, rank: int = 0, world: int = 1) -> Callable[[], Tensor]:
@@ -399,10 +477,11 @@ def main(argv=None) -> None:
             if device.type == "cuda":
                 torch.cuda.synchronize()
             dt = time.perf_counter() - t0
-            rec = {k: float(v) for k, v in logs.items()}
+            rec = {k: float(v) if v.numel() == 1 else v.tolist() for k, v in logs.items()}
             rec.update(step=trainer.step, img_per_s=50 * cfg.batch_size / dt)
             print(json.dumps(rec), flush=True)
             t0 = time.perf_counter()
+    trainer.flush()
 
 
 if __name__ == "__main__":

@@ -389,8 +389,10 @@ def test_trainer_recipes_golden(dev, golden, name):
 
 def test_trainer_graph_matches_host_launches_n_disc_and_grad_accum(dev, golden):
     """The iteration replayed as HIP graphs against the same iteration launched from the host, where a step has several
-    discriminator passes: n_disc = 2 (a blocking gradient cut inside the captured iteration) and grad_accum = 2 (the
-    gradient arena keeps accumulating across two backward passes before the exchange).  DCGAN WGAN-GP; same seed, so the
+    discriminator passes: n_disc = 2 (every D step's gradient cut is followed by the generator forward the next pass
+    needs), grad_accum = 2 (the gradient arena keeps accumulating across two backward passes before the exchange), and the
+    deferred generator update of multi-rank runs (its all-reduce left in flight over the iteration boundary; the EMA copy
+    is compared too).  DCGAN WGAN-GP; same seed, so the
     device generator hands both trainers the same draws; five iterations (two of them before the capture), four with Adam.
     SGD: the update is proportional to the gradient, so everything agrees to rounding.  Adam with beta1 = 0 turns the
     rounding-sized gradient components behind the generator's BatchNorm (the direction that rescales a channel has zero
@@ -398,7 +400,8 @@ def test_trainer_graph_matches_host_launches_n_disc_and_grad_accum(dev, golden):
     split-K reductions add in arrival order, and the fifth iteration is 16x further apart than the fourth)."""
     g = golden("trainer_recipes")["dcgan_wgan_gp"]
     for over in (dict(n_disc=2), dict(n_disc=1, grad_accum=2), dict(n_disc=2, optimizer="SGD", optimizer_kwargs={}, lr=1e-3),
-                 dict(n_disc=1, grad_accum=2, optimizer="SGD", optimizer_kwargs={}, lr=1e-3)):
+                 dict(n_disc=1, grad_accum=2, optimizer="SGD", optimizer_kwargs={}, lr=1e-3),
+                 dict(n_disc=2, defer_g_step=True, optimizer="SGD", optimizer_kwargs={}, lr=1e-3), dict(n_disc=1, defer_g_step=True)):
         runs = []
         for graph in (False, True):
             torch.manual_seed(77)
@@ -418,8 +421,15 @@ def test_trainer_graph_matches_host_launches_n_disc_and_grad_accum(dev, golden):
             if graph:
                 assert tr._graph is not None
                 cuts = [cut[0] for _, cut in tr._graph if cut is not None]
-                assert cuts == (["reduce", "start", "wait", "reduce"] if over["n_disc"] == 2 else ["reduce", "reduce"]), cuts
-            runs.append((losses, {k: v.detach().clone() for k, v in tr.disc.state_dict().items()}, {k: v.detach().clone() for k, v in tr.gen.state_dict().items()}))
+                want = ["start", "wait"] * over["n_disc"] + ["reduce"]
+                if over.get("defer_g_step"):
+                    want = ["finish_g"] + want[:-1] + ["start_g"]
+                assert cuts == want, cuts
+                tr.flush()  # (the deferred generator update of the last iteration)
+            gsd = {k: v.detach().clone() for k, v in tr.gen.state_dict().items()}
+            gsd.update({"ema." + k: v.detach().clone() for k, v in tr.gen_ema.ema_model.state_dict().items()})
+            runs.append((losses, {k: v.detach().clone() for k, v in tr.disc.state_dict().items()}, gsd))
+            assert int(tr.gen_ema.counter) == len(losses)
         (l0, d0, g0), (l1, d1, g1) = runs
         for a, b in zip(l0, l1):
             assert len(a) == over["n_disc"] * over.get("grad_accum", 1) + 1
