@@ -332,6 +332,8 @@ def micro_leg(device):
     big = out["32x16x1024x1024"]
     return dict(shapes=out, diff_augment_256x3x256x256=da, peak_gbs=HBM_PEAK_GBS, fir3_frac_at_largest=round(big["fir3_gbs"] / HBM_PEAK_GBS, 4),
                 bias_lrelu_frac_at_largest=round(big["bias_lrelu_gbs"] / HBM_PEAK_GBS, 4),
+                down2_fir4_frac_at_largest=round(big["down2_fir4_gbs"] / HBM_PEAK_GBS, 4),
+                up2_fir4_frac_at_32x64x256x256=round(out["32x64x256x256"]["up2_fir4_gbs"] / HBM_PEAK_GBS, 4),
                 method="*_gbs: raw kernel launches, events over 100 (20) launches, algorithmic bytes (in + out) * 2; "
                        "its_per_s_n_backward: benchmark_upfirdn2d.py:15-29 on UpFIRDn2d.apply, bf16 channels_last")
 

@@ -191,6 +191,8 @@ int gan_finalize_dw(const float* ws, int S, int taps, int Cout, int Cin, const D
                     float bias_gain = 1.f);
 
 // upfirdn_mfma.hip: bf16 upfirdn2d with the FIR as banded matrix products on MFMA.  1 / 0 / < 0 as above.
+int gan_upfirdn2d_direct(const void* x, const float* taps, void* y, int N, int H, int W, int C, int ky, int kx, int up, int down,
+                         int px1, int py1, int Ho, int Wo, hipStream_t st);
 int gan_upfirdn2d_mfma(const void* x, const float* taps, void* y, int N, int H, int W, int C, int ky, int kx, int up,
                        int down, int px1, int py1, int Ho, int Wo, hipStream_t st);
 

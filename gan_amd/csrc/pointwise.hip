@@ -138,6 +138,9 @@ static int upfirdn2d_launch(const void* x, const float* taps, void* y, int N, in
     const int64_t total = (int64_t)N * Ho * Wo * (vec ? C / VV : C);
     if (total == 0) return GAN_OK;
     if constexpr (sizeof(T) == 2) {
+        // a factor of two: direct polyphase kernel (upfirdn_direct.hip); stride 1: the matrix-core kernel
+        const int rd = gan_upfirdn2d_direct(x, taps, y, N, H, W, C, ky, kx, up, down, px1, py1, Ho, Wo, st);
+        if (rd != 0) return rd < 0 ? rd : GAN_OK;
         const int rc = gan_upfirdn2d_mfma(x, taps, y, N, H, W, C, ky, kx, up, down, px1, py1, Ho, Wo, st);
         if (rc != 0) return rc < 0 ? rc : GAN_OK;
     }
