@@ -10,6 +10,7 @@
 // All three are bilinear in their two tensor arguments and closed under differentiation (fwd <-> dgrad <-> wgrad), so
 // R1's double backward through the first layer runs on them too.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -17,6 +18,8 @@ constexpr int RTPB = 256;
 constexpr int RGB_MAXC = 4;       // image channels
 constexpr int RGB_WG_BLOCKS = 1024;
 constexpr unsigned RGB_FWD_PX = 4;  // pixels per thread of the forward kernel
+constexpr int RGB_DG_IT = 1;        // pixel groups per workgroup of the input-gradient kernel (4: 171 -> 180 us at 256 x 256, batch 256)
+constexpr int RGB_DG16_IT = 2;      // pixels per thread of its 16-channel variant
 
 template <typename T>
 __device__ __forceinline__ float ldf(const T* p) { return (float)*p; }
@@ -86,47 +89,59 @@ __global__ void __launch_bounds__(RTPB) rgb_fwd_k(const TI* __restrict__ x, int6
 // the Cin-channel output (6 bytes per pixel for RGB in bf16) leaves as contiguous 4-byte stores.
 template <typename T, int CV>
 __global__ void __launch_bounds__(RTPB) rgb_dgrad_k(const T* __restrict__ gy, const float* __restrict__ wgt, T* __restrict__ gx, int64_t NP, int Cin) {
-    constexpr int COUT = CV * 8, PPB = RTPB / CV;  // pixels per workgroup
+    // RGB_DG_IT pixel groups per workgroup, their loads issued before the first product (round 3: one group per workgroup
+    // was 131 k workgroups of two barriers and a weight load each at 256 x 256, batch 256: 3.6 TB/s)
+    constexpr int COUT = CV * 8, PPB = RTPB / CV, IT = RGB_DG_IT;  // PPB pixels per group
     __shared__ float4 wl[COUT];
-    __shared__ __attribute__((aligned(16))) T ol[PPB * RGB_MAXC];
+    __shared__ __attribute__((aligned(16))) T ol[IT * PPB * RGB_MAXC];
     for (int i = threadIdx.x; i < COUT; i += RTPB) {
         float t[4] = {0.f, 0.f, 0.f, 0.f};
         for (int c = 0; c < Cin; ++c) t[c] = wgt[i * Cin + c];
         wl[i] = make_float4(t[0], t[1], t[2], t[3]);
     }
-    __syncthreads();
     const int lp = threadIdx.x / CV, ch = threadIdx.x % CV;
-    const int64_t pix0 = (int64_t)blockIdx.x * PPB;
-    const int64_t pix = pix0 + lp;
-    float acc[RGB_MAXC] = {0.f, 0.f, 0.f, 0.f};
-    if (pix < NP) {
-        float g[8];
-        if constexpr (sizeof(T) == 2) {
-            load_f<T, 8>(gy + pix * COUT + ch * 8, g);
-        } else {
-            float lo[4], hi[4];
-            load_f<T, 4>(gy + pix * COUT + ch * 8, lo);
-            load_f<T, 4>(gy + pix * COUT + ch * 8 + 4, hi);
+    const int64_t pix0 = (int64_t)blockIdx.x * (PPB * IT);
+    float g[IT][8];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { g[j] = lo[j]; g[4 + j] = hi[j]; }
-        }
+    for (int it = 0; it < IT; ++it) {
+        const int64_t pix = pix0 + it * PPB + lp;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float4 w4 = wl[ch * 8 + j];
-            acc[0] = fmaf(g[j], w4.x, acc[0]); acc[1] = fmaf(g[j], w4.y, acc[1]);
-            acc[2] = fmaf(g[j], w4.z, acc[2]); acc[3] = fmaf(g[j], w4.w, acc[3]);
+        for (int j = 0; j < 8; ++j) g[it][j] = 0.f;
+        if (pix < NP) {
+            if constexpr (sizeof(T) == 2) {
+                load_f<T, 8>(gy + pix * COUT + ch * 8, g[it]);
+            } else {
+                float lo[4], hi[4];
+                load_f<T, 4>(gy + pix * COUT + ch * 8, lo);
+                load_f<T, 4>(gy + pix * COUT + ch * 8 + 4, hi);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { g[it][j] = lo[j]; g[it][4 + j] = hi[j]; }
+            }
         }
     }
-#pragma unroll
-    for (int off = 1; off < CV; off <<= 1)
-#pragma unroll
-        for (int c = 0; c < RGB_MAXC; ++c) acc[c] += __shfl_xor(acc[c], off);
-    if (ch == 0)
-        for (int c = 0; c < Cin; ++c) ol[lp * Cin + c] = (T)acc[c];
     __syncthreads();
-    // the workgroup's PPB * Cin outputs are contiguous in gx (channels-last, Cin channels)
+    float4 wr[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) wr[j] = wl[ch * 8 + j];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        float acc[RGB_MAXC] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            acc[0] = fmaf(g[it][j], wr[j].x, acc[0]); acc[1] = fmaf(g[it][j], wr[j].y, acc[1]);
+            acc[2] = fmaf(g[it][j], wr[j].z, acc[2]); acc[3] = fmaf(g[it][j], wr[j].w, acc[3]);
+        }
+#pragma unroll
+        for (int off = 1; off < CV; off <<= 1)
+#pragma unroll
+            for (int c = 0; c < RGB_MAXC; ++c) acc[c] += __shfl_xor(acc[c], off);
+        if (ch == 0)
+            for (int c = 0; c < Cin; ++c) ol[(it * PPB + lp) * Cin + c] = (T)acc[c];
+    }
+    __syncthreads();
+    // the workgroup's IT * PPB * Cin outputs are contiguous in gx (channels-last, Cin channels)
     int64_t live = NP - pix0;
-    if (live > PPB) live = PPB;
+    if (live > PPB * IT) live = PPB * IT;
     const int nel = (int)live * Cin;
     T* __restrict__ dst = gx + pix0 * Cin;
     constexpr int EPW = 4 / sizeof(T);  // elements per 4-byte word
@@ -138,46 +153,124 @@ __global__ void __launch_bounds__(RTPB) rgb_dgrad_k(const T* __restrict__ gy, co
     }
 }
 
+// dgrad, Cout = 16 (round 3): a lane owns a whole pixel -- 32 contiguous bytes, two 16-byte loads, a wave's loads one 2 KB
+// run -- so there is no cross-lane fold; RGB_DG16_IT pixels per thread with their loads issued up front.
+template <typename T>
+__global__ void __launch_bounds__(RTPB) rgb_dgrad16_k(const T* __restrict__ gy, const float* __restrict__ wgt, T* __restrict__ gx, int64_t NP, int Cin) {
+    constexpr int IT = RGB_DG16_IT;
+    __shared__ float4 wl[16];
+    __shared__ __attribute__((aligned(16))) T ol[IT * RTPB * RGB_MAXC];
+    if (threadIdx.x < 16) {
+        float t[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < Cin; ++c) t[c] = wgt[threadIdx.x * Cin + c];
+        wl[threadIdx.x] = make_float4(t[0], t[1], t[2], t[3]);
+    }
+    const int64_t pix0 = (int64_t)blockIdx.x * (RTPB * IT);
+    float g[IT][16];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int64_t pix = pix0 + it * RTPB + threadIdx.x;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) g[it][j] = 0.f;
+        if (pix < NP) {
+            if constexpr (sizeof(T) == 2) {
+                float lo[8], hi[8];
+                load_f<T, 8>(gy + pix * 16, lo);
+                load_f<T, 8>(gy + pix * 16 + 8, hi);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { g[it][j] = lo[j]; g[it][8 + j] = hi[j]; }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float v4[4];
+                    load_f<T, 4>(gy + pix * 16 + 4 * q, v4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) g[it][4 * q + j] = v4[j];
+                }
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        float acc[RGB_MAXC] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const float4 w4 = wl[j];  // (the same address for every lane: a broadcast)
+            acc[0] = fmaf(g[it][j], w4.x, acc[0]); acc[1] = fmaf(g[it][j], w4.y, acc[1]);
+            acc[2] = fmaf(g[it][j], w4.z, acc[2]); acc[3] = fmaf(g[it][j], w4.w, acc[3]);
+        }
+        for (int c = 0; c < Cin; ++c) ol[(it * RTPB + threadIdx.x) * Cin + c] = (T)acc[c];
+    }
+    __syncthreads();
+    int64_t live = NP - pix0;
+    if (live > RTPB * IT) live = RTPB * IT;
+    const int nel = (int)live * Cin;
+    T* __restrict__ dst = gx + pix0 * Cin;
+    constexpr int EPW = 4 / sizeof(T);
+    if ((pix0 * Cin * (int64_t)sizeof(T)) % 4 == 0) {
+        for (int i = threadIdx.x; i < nel / EPW; i += RTPB) reinterpret_cast<uint32_t*>(dst)[i] = reinterpret_cast<const uint32_t*>(ol)[i];
+        for (int i = (nel / EPW) * EPW + threadIdx.x; i < nel; i += RTPB) dst[i] = ol[i];
+    } else {
+        for (int i = threadIdx.x; i < nel; i += RTPB) dst[i] = ol[i];
+    }
+}
+
 // wgrad stage 1: a workgroup walks pixels p = block, block + grid, ...; a thread owns one pixel at a time and keeps Cout x Cin
 // partial sums for ONE 8-channel chunk of Cout (blockIdx.y), folded over the workgroup with shuffles + LDS.
-template <typename TX, typename TG>
+template <typename TX, typename TG, int CH>
 __global__ void __launch_bounds__(RTPB) rgb_wgrad_k(const TX* __restrict__ x, int64_t sn, int64_t sc, int64_t sh, int64_t sw, unsigned W, int lin,
                                                     const TG* __restrict__ gy, float* __restrict__ ws, unsigned NP, unsigned HW, int Cin, int Cout,
                                                     int want_bias) {
     // want_bias: the free channel slot Cin (< RGB_MAXC) carries a constant 1, so column Cin of the result is sum(gy): the
-    // bias gradient out of the products the kernel forms anyway (rows of ws are then Cin + 1 wide)
+    // bias gradient out of the products the kernel forms anyway (rows of ws are then Cin + 1 wide).
+    // CH = 16 where Cout allows (round 3): a lane reads 32 contiguous bytes of its pixel's gradient -- with Cout = 16 a wave's
+    // loads are one 2 KB run where the 8-channel chunks of two workgroups each took every other 16 bytes -- and the image
+    // is read once instead of once per chunk; two pixels per thread are in flight.
     const int CW = Cin + want_bias;
-    __shared__ float red[RTPB / 64][8 * RGB_MAXC];
-    const int c8 = blockIdx.y * 8;
-    float acc[8][RGB_MAXC];
+    __shared__ float red[RTPB / 64][CH * RGB_MAXC];
+    const int c8 = blockIdx.y * CH;
+    float acc[CH][RGB_MAXC];
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
+    for (int j = 0; j < CH; ++j)
 #pragma unroll
         for (int c = 0; c < RGB_MAXC; ++c) acc[j][c] = 0.f;
-    for (unsigned pix = blockIdx.x * RTPB + threadIdx.x; pix < NP; pix += gridDim.x * RTPB) {
-        const unsigned n = pix / HW, p = pix - n * HW;
+    auto load_px = [&](unsigned pix, float (&xv)[RGB_MAXC], float (&g)[CH]) {
+        const bool ok = pix < NP;
+        const unsigned pq = ok ? pix : 0u;
+        const unsigned n = pq / HW, p = pq - n * HW;
         const TX* __restrict__ xp = x + rgb_xoff(n, p, sn, sh, sw, W, lin);
-        float xv[RGB_MAXC];
 #pragma unroll
-        for (int c = 0; c < RGB_MAXC; ++c) xv[c] = c < Cin ? ldf(xp + c * sc) : (c == Cin && want_bias ? 1.f : 0.f);
-        float g[8];
-        if constexpr (sizeof(TG) == 2) {
-            load_f<TG, 8>(gy + (int64_t)pix * Cout + c8, g);
-        } else {
-            float lo[4], hi[4];
-            load_f<TG, 4>(gy + (int64_t)pix * Cout + c8, lo);
-            load_f<TG, 4>(gy + (int64_t)pix * Cout + c8 + 4, hi);
+        for (int c = 0; c < RGB_MAXC; ++c) xv[c] = c < Cin ? (ok ? ldf(xp + c * sc) : 0.f) : (c == Cin && want_bias && ok ? 1.f : 0.f);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { g[j] = lo[j]; g[4 + j] = hi[j]; }
+        for (int h = 0; h < CH / 8; ++h) {
+            float g8[8];
+            if constexpr (sizeof(TG) == 2) {
+                load_f<TG, 8>(gy + (int64_t)pq * Cout + c8 + 8 * h, g8);
+            } else {
+                float lo[4], hi[4];
+                load_f<TG, 4>(gy + (int64_t)pq * Cout + c8 + 8 * h, lo);
+                load_f<TG, 4>(gy + (int64_t)pq * Cout + c8 + 8 * h + 4, hi);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { g8[j] = lo[j]; g8[4 + j] = hi[j]; }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) g[8 * h + j] = ok ? g8[j] : 0.f;
         }
+    };
+    const unsigned stride = gridDim.x * RTPB;
+    for (unsigned pix = blockIdx.x * RTPB + threadIdx.x; pix < NP; pix += 2 * stride) {
+        float xa[RGB_MAXC], xb[RGB_MAXC], ga[CH], gb[CH];
+        load_px(pix, xa, ga);
+        load_px(pix + stride, xb, gb);
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
+        for (int j = 0; j < CH; ++j)
 #pragma unroll
-            for (int c = 0; c < RGB_MAXC; ++c) acc[j][c] = fmaf(g[j], xv[c], acc[j][c]);
+            for (int c = 0; c < RGB_MAXC; ++c) acc[j][c] = fmaf(gb[j], xb[c], fmaf(ga[j], xa[c], acc[j][c]));
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
+    for (int j = 0; j < CH; ++j)
 #pragma unroll
         for (int c = 0; c < RGB_MAXC; ++c) {
             float v = acc[j][c];
@@ -185,7 +278,7 @@ __global__ void __launch_bounds__(RTPB) rgb_wgrad_k(const TX* __restrict__ x, in
             if (lane == 0) red[wave][j * RGB_MAXC + c] = v;
         }
     __syncthreads();
-    if (threadIdx.x < 8 * RGB_MAXC) {
+    if (threadIdx.x < CH * RGB_MAXC) {
         float t = 0.f;
         for (int wv = 0; wv < RTPB / 64; ++wv) t += red[wv][threadIdx.x];
         const int j = threadIdx.x / RGB_MAXC, c = threadIdx.x % RGB_MAXC;
@@ -252,9 +345,18 @@ extern "C" int gan_rgb_conv1x1_dgrad(const void* gy, const float* w, void* gx, i
     GAN_CHECK_ARG(gy && w && gx && ((uintptr_t)gy % 16) == 0, "rgb_conv1x1_dgrad: null or unaligned pointer");
     const int CV = Cout / 8;
     GAN_CHECK_ARG(CV == 1 || CV == 2 || CV == 4 || CV == 8, "rgb_conv1x1_dgrad: Cout must be 8, 16, 32 or 64");
-    const int64_t blocks = ceil_div64(NP, RTPB / CV);
+    const int64_t blocks = ceil_div64(NP, (int64_t)(RTPB / CV) * RGB_DG_IT);
     GAN_CHECK_ARG(blocks < (1LL << 31), "rgb_conv1x1_dgrad: tensor too large");
     hipStream_t st = (hipStream_t)stream;
+    static const bool dg16 = !(getenv("GAN_AMD_RGB_DG16") && atoi(getenv("GAN_AMD_RGB_DG16")) == 0);  // A/B runs
+    if (Cout == 16 && dg16) {
+        const int64_t b16 = ceil_div64(NP, (int64_t)RTPB * RGB_DG16_IT);
+        GAN_CHECK_ARG(b16 < (1LL << 31), "rgb_conv1x1_dgrad: tensor too large");
+        if (dtype == GAN_F32) hipLaunchKernelGGL(rgb_dgrad16_k<float>, dim3((unsigned)b16), dim3(RTPB), 0, st, (const float*)gy, w, (float*)gx, NP, Cin);
+        else hipLaunchKernelGGL(rgb_dgrad16_k<bf16>, dim3((unsigned)b16), dim3(RTPB), 0, st, (const bf16*)gy, w, (bf16*)gx, NP, Cin);
+        GAN_CHECK_LAUNCH("rgb_conv1x1_dgrad");
+        return GAN_OK;
+    }
 #define RGB_DG3(T_, CV_) hipLaunchKernelGGL((rgb_dgrad_k<T_, CV_>), dim3((unsigned)blocks), dim3(RTPB), 0, st, (const T_*)gy, w, (T_*)gx, NP, Cin)
 #define RGB_DG(T_)                   \
     do {                             \
@@ -298,16 +400,23 @@ extern "C" int gan_rgb_conv1x1_wgrad(const void* x, int x_dtype, int64_t sn, int
     if (nb > RGB_WG_BLOCKS) nb = RGB_WG_BLOCKS;
     if (nb < 1) nb = 1;
     GAN_CHECK_ARG(workspace && workspace_floats >= nb * L, "rgb_conv1x1_wgrad: needs a workspace of gan_rgb_conv1x1_wgrad_workspace(...) floats");
-    const dim3 grid((unsigned)nb, (unsigned)(Cout / 8));
-    GAN_CHECK_ARG(NP < (1LL << 31), "rgb_conv1x1_wgrad: tensor too large");
+    const int CH = (Cout % 16 == 0) ? 16 : 8;  // output channels per thread
+    const dim3 grid((unsigned)nb, (unsigned)(Cout / CH));
+    GAN_CHECK_ARG(NP < (1LL << 31), "rgb_conv1x1_wgrad: tensor too large");  // (pix + 2 * stride stays below 2^32)
     const int lin = sh == (int64_t)W * sw;
-#define RGB_WG(TX, TG) \
-    hipLaunchKernelGGL((rgb_wgrad_k<TX, TG>), grid, dim3(RTPB), 0, st, (const TX*)x, sn, sc, sh, sw, (unsigned)W, lin, (const TG*)gy, workspace, (unsigned)NP, (unsigned)(H * W), Cin, Cout, want_bias)
+#define RGB_WG2(TX, TG, CH_) \
+    hipLaunchKernelGGL((rgb_wgrad_k<TX, TG, CH_>), grid, dim3(RTPB), 0, st, (const TX*)x, sn, sc, sh, sw, (unsigned)W, lin, (const TG*)gy, workspace, (unsigned)NP, (unsigned)(H * W), Cin, Cout, want_bias)
+#define RGB_WG(TX, TG)                      \
+    do {                                    \
+        if (CH == 16) RGB_WG2(TX, TG, 16);  \
+        else RGB_WG2(TX, TG, 8);            \
+    } while (0)
     if (x_dtype == GAN_F32 && gy_dtype == GAN_F32) RGB_WG(float, float);
     else if (x_dtype == GAN_F32) RGB_WG(float, bf16);
     else if (gy_dtype == GAN_F32) RGB_WG(bf16, float);
     else RGB_WG(bf16, bf16);
 #undef RGB_WG
+#undef RGB_WG2
     GAN_CHECK_LAUNCH("rgb_conv1x1_wgrad");
     hipLaunchKernelGGL(rgb_wgrad_fold_k, dim3((unsigned)L), dim3(64), 0, st, workspace, dw, dbias, (int)nb, L, Cin, CW);
     GAN_CHECK_LAUNCH("rgb_conv1x1_wgrad(fold)");
