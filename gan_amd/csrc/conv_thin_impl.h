@@ -72,29 +72,31 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t thin_rsrc(const void* p, unsig
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, p ? bytes : 0u, 0x00020000);
 }
 
-template <int CIN, int COUT, int KS, int RPW>
+template <int CIN, int COUT, int KS, int RPW, int NW = 4>
 struct ThinCfg {
+    static constexpr int NT = 64 * NW;          // threads (NW waves, RPW output rows each)
     static constexpr int CP = CIN / 8;          // 16-byte channel chunks per pixel
-    static constexpr int TH = 4 * RPW, TW = 32; // output tile
+    static constexpr int TH = NW * RPW, TW = 32; // output tile
     static constexpr int HH = TH + KS - 1, HWD = TW + KS - 1, NPIX = HH * HWD;
     static constexpr int PLANE = (NPIX * 16 + 255) / 256 * 256;  // bytes per chunk plane, 256-B multiple
     static constexpr int KTOT = KS * KS * CIN, NSTEP = (KTOT + 31) / 32, KPAD = NSTEP * 32;
     static constexpr int FCO = COUT / 16, FPX = 2 * RPW;
     static constexpr int NCHUNK = ((NPIX + 7) / 8) * 8 * CP;
-    static constexpr int NLD = (NCHUNK + 255) / 256;
+    static constexpr int NLD = (NCHUNK + NT - 1) / NT;
     static constexpr int X_BYTES = CP * PLANE;
     static constexpr int W_BYTES = KPAD * COUT * 2;
     static constexpr int P_BYTES = 3 * COUT * 4;  // bias, noise scale, this tile's demodulation row (fp32)
-    static constexpr int D_BYTES = 256 * 16;      // per-thread dump slot for staging chunks past the halo
+    static constexpr int D_BYTES = NT * 16;       // per-thread dump slot for staging chunks past the halo
     static constexpr int LDS_BYTES = X_BYTES + W_BYTES + P_BYTES + D_BYTES;
 };
 
 // VEC: Cout % 4 == 0, 8-byte stores; !VEC (to-/from-RGB, Cout = 3): 2-byte stores.  A template parameter, not
 // a branch: an if/else with different stores on its two sides makes hipcc forget how many memory
 // instructions are in flight (it then waits for all of them).
-template <int CIN, int COUT, int KS, int RPW, int MODE, bool VEC>
-__global__ void __launch_bounds__(256, 2) conv_thin_k(const ThinArgs p) {
-    typedef ThinCfg<CIN, COUT, KS, RPW> C;
+template <int CIN, int COUT, int KS, int RPW, int MODE, bool VEC, int NW = 4>
+__global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) conv_thin_k(const ThinArgs p) {
+    typedef ThinCfg<CIN, COUT, KS, RPW, NW> C;
+    constexpr int NT = C::NT;
     constexpr int CP = C::CP, TH = C::TH, HWD = C::HWD, NPIX = C::NPIX, PLANE = C::PLANE;
     constexpr int NSTEP = C::NSTEP, KPAD = C::KPAD, FCO = C::FCO, FPX = C::FPX, NLD = C::NLD;
     constexpr bool G = MODE == THIN_G, AUX = MODE == THIN_DA, POOL = MODE == THIN_DP || MODE == THIN_DPR, RES = MODE == THIN_DPR;
@@ -112,7 +114,7 @@ __global__ void __launch_bounds__(256, 2) conv_thin_k(const ThinArgs p) {
     const bf16* __restrict__ wt = (const bf16*)p.wt;
 
     // ---- weights -> LDS as [k/8][co][8]; rows co >= Cout are zero ------------------------------
-    for (int idx = tid; idx < (KPAD / 8) * COUT; idx += 256) {
+    for (int idx = tid; idx < (KPAD / 8) * COUT; idx += NT) {
         const int co = idx % COUT;
         const int kc = idx / COUT;
         uint4 v = make_uint4(0, 0, 0, 0);
@@ -140,12 +142,12 @@ __global__ void __launch_bounds__(256, 2) conv_thin_k(const ThinArgs p) {
 
     // ---- halo loader: chunk idx -> (pixel, channel chunk); 8 consecutive lanes = 8 consecutive
     // pixels of one chunk plane (conflict-free ds_write_b128), 8*CP lanes = one contiguous run.
-    // 256 % (8*CP) == 0, so a thread's channel chunk c is the same for all of its slots. ----------
+    // NT % (8*CP) == 0, so a thread's channel chunk c is the same for all of its slots. ----------
     const int cch = (tid % (8 * CP)) >> 3;
     int hyx[NLD];  // (hy << 16) | hx of slot i, or -1 past the halo
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
-        const int idx = i * 256 + tid;
+        const int idx = i * NT + tid;
         const int pix = (idx / (8 * CP)) * 8 + (idx & 7);
         const int hy = pix / HWD, hx = pix - hy * HWD;
         hyx[i] = pix < NPIX ? (hy << 16) | hx : -1;
@@ -177,7 +179,7 @@ __global__ void __launch_bounds__(256, 2) conv_thin_k(const ThinArgs p) {
         if (G && tid < COUT) pl[2 * COUT + tid] = p.out_scale ? osc_reg : 1.f;
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
-            const int idx = i * 256 + tid;
+            const int idx = i * NT + tid;
             const int pix = (idx / (8 * CP)) * 8 + (idx & 7);
             uint4 v = __builtin_bit_cast(uint4, reg[i]);
             if (!G && p.fu.in_slope != 1.f) v = lrelu_chunk(v, p.fu.in_slope, bf16());
@@ -353,9 +355,9 @@ __global__ void __launch_bounds__(256, 2) conv_thin_k(const ThinArgs p) {
     }
 }
 
-template <int CIN, int COUT, int KS, int RPW, bool VEC>
+template <int CIN, int COUT, int KS, int RPW, bool VEC, int NW = 4>
 int launch_thin_v(ThinArgs a, hipStream_t st) {
-    typedef ThinCfg<CIN, COUT, KS, RPW> C;
+    typedef ThinCfg<CIN, COUT, KS, RPW, NW> C;
     static_assert(C::LDS_BYTES <= 160 * 1024, "tile does not fit LDS");
     a.tiles_x = (a.Wo + 31) / 32;
     a.tiles_y = (a.Ho + C::TH - 1) / C::TH;
@@ -364,12 +366,12 @@ int launch_thin_v(ThinArgs a, hipStream_t st) {
     static int per_cu = 0;
     if (per_cu == 0) {
         int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_thin_k<CIN, COUT, KS, RPW, THIN_MODE, VEC>, 256, 0) != hipSuccess || nb < 1) nb = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_thin_k<CIN, COUT, KS, RPW, THIN_MODE, VEC, NW>, C::NT, 0) != hipSuccess || nb < 1) nb = 1;
         per_cu = nb > 8 ? 8 : nb;
     }
     int64_t grid = 256LL * per_cu;
     if (grid > ntiles) grid = ntiles;
-    hipLaunchKernelGGL((conv_thin_k<CIN, COUT, KS, RPW, THIN_MODE, VEC>), dim3((unsigned)grid), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((conv_thin_k<CIN, COUT, KS, RPW, THIN_MODE, VEC, NW>), dim3((unsigned)grid), dim3(C::NT), 0, st, a);
     GAN_CHECK_LAUNCH("conv2d_fwd(thin)");
     return GAN_OK;
 }
@@ -402,6 +404,16 @@ int pick_cin(const ThinArgs& a, int Cin, hipStream_t st) {
             // (not the pooled mode: a wave pools the row pair it owns)
             if constexpr (KS == 3 && THIN_MODE != THIN_DP && THIN_MODE != THIN_DPR) {
                 if (a.Cout <= 32 && getenv("GAN_AMD_THIN64_RPW2") == nullptr) return pick_cout<64, KS, 1>(a, st);
+            }
+            // Cout = 64, 3 x 3: the 74 KB weight image leaves one workgroup per CU -- as 4 waves that is ONE wave per SIMD (PMC:
+            // MFMA pipe 33 % busy).  Measured in round 3 and NOT the default (GAN_AMD_THIN64_W8=1 selects it): 8 waves x 2 rows =
+            // 16 x 32 tiles, halo 78 KB + weights 74 KB, two waves per SIMD: 102.9 -> 99.0 us on 64 -> 64 @ 64^2, batch 256
+            // (pooled 85.4 -> 79.3), the train step unchanged (48.85 / 48.95 ms, same box) -- the kernel's LDS reads and its
+            // MFMAs each take ~31 us at 2.4 GHz and the second wave does not make them overlap.  16-row tiles on 4 waves
+            // (RPW = 4): 172 us.
+            if constexpr (KS == 3) {
+                static const bool w8 = getenv("GAN_AMD_THIN64_W8") && atoi(getenv("GAN_AMD_THIN64_W8")) == 1;
+                if (w8 && a.Cout > 32 && (a.Cout & 3) == 0) return launch_thin_v<64, 64, KS, 2, true, 8>(a, st);
             }
             return pick_cout<64, KS, 2>(a, st);
     }

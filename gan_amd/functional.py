@@ -1981,7 +1981,8 @@ class InstNormAffineFn(Function):
     (stylegan.py:33-34).  Forward: statistics kernel + one affine pass; backward: two channel reductions + one pass
         gx = r * gamma * (gz - mean(gz) - xhat * mean(gz * xhat)),   gz = g * lrelu'(y),
     written as gz * a1 + x * a2 + a3 with per-(sample, channel) coefficients (kernel gan_chan_lin2).
-    First order only: the generator never sits inside a create_graph region (train_celeba.py:128-129)."""
+    The kernels serve the first order (the generator never sits inside a create_graph region, train_celeba.py:128-129);
+    under create_graph the backward is the same map out of differentiable library ops."""
 
     @staticmethod
     def forward(ctx, x, gamma, beta, slope, eps):
@@ -2000,16 +2001,25 @@ class InstNormAffineFn(Function):
         check(_run("chan_affine", 0, _nbytes(xc, y),
                    lambda: lib.gan_chan_affine(ptr(xc), ptr(a), ptr(b), ptr(y), n, h * w, c, float(slope), dtype_code(xc), stream_of(xc)), (n, c, h, w)),
               "gan_chan_affine")
-        ctx.save_for_backward(xc, g32, mean, rstd, y if slope != 1.0 else None)
+        ctx.save_for_backward(xc, g32, mean, rstd, y if slope != 1.0 else None, x, gamma, beta)
         ctx.slope = slope
+        ctx.eps = eps
         ctx.meta = (gamma.shape, gamma.dtype, beta.shape, beta.dtype, x.dtype)
         return y
 
     @staticmethod
     def backward(ctx, g):
+        xc, g32, mean, rstd, y, x_in, gamma_in, beta_in = ctx.saved_tensors
         if torch.is_grad_enabled():
-            raise _lib.GanAmdError("AdaIN: second-order derivatives are not implemented (generator-side op)")
-        xc, g32, mean, rstd, y = ctx.saved_tensors
+            # a create_graph region (gradient penalties through a normalised network): the same map out of differentiable
+            # library ops, so any order of derivative exists -- at library speed; the kernels serve the first order
+            with torch.enable_grad():
+                n, c = x_in.shape[:2]
+                z = torch.nn.functional.instance_norm(x_in.float(), eps=ctx.eps) * gamma_in.float().reshape(n, c, 1, 1) + beta_in.float().reshape(n, c, 1, 1)
+                z = torch.nn.functional.leaky_relu(z, ctx.slope) if ctx.slope != 1.0 else z
+                wanted = [t for i, t in enumerate((x_in, gamma_in, beta_in)) if _need(ctx, i)]
+                grads = iter(torch.autograd.grad(z, wanted, g.float(), create_graph=True, allow_unused=True))
+            return tuple(next(grads) if _need(ctx, i) else None for i in range(3)) + (None, None)
         n, c, h, w = xc.shape
         hw = float(h * w)
         gc = as_cl(g.detach().to(xc.dtype))
@@ -2040,7 +2050,8 @@ def instance_norm_affine(x: Tensor, gamma: Tensor, beta: Tensor, slope: float = 
 class LayerNorm2dFn(Function):
     """y = lrelu_slope( LayerNorm_over_channels(x) * w[c] + b[c] ) per pixel (modelling/common.py:19-24, eps 1e-5) with the
     LeakyReLU that follows it in the Progressive-GAN generator (progressive_gan.py:89-90,124-125): one launch forward,
-    one backward (input gradient + both parameter gradients).  First order only (generator-side op)."""
+    one backward (input gradient + both parameter gradients).  Under create_graph (a gradient penalty through
+    DcGanDiscriminator(norm="layer")) the backward is the same map out of differentiable library ops."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, slope, eps):
@@ -2054,16 +2065,26 @@ class LayerNorm2dFn(Function):
         check(_run("layernorm2d", 0, _nbytes(xc, y),
                    lambda: lib.gan_layernorm2d_fwd(ptr(xc), ptr(w32), ptr(b32), ptr(y), ptr(stats), n * h * w, c, float(eps), float(slope),
                                                    dtype_code(xc), stream_of(xc)), (n, c, h, w)), "gan_layernorm2d_fwd")
-        ctx.save_for_backward(xc, w32, stats, y if slope != 1.0 else None)
+        ctx.save_for_backward(xc, w32, stats, y if slope != 1.0 else None, x, weight, bias)
         ctx.slope = slope
+        ctx.eps = eps
         ctx.meta = (weight.shape, weight.dtype, bias.shape, bias.dtype, x.dtype)
         return y
 
     @staticmethod
     def backward(ctx, g):
+        xc, w32, stats, y, x_in, w_in, b_in = ctx.saved_tensors
         if torch.is_grad_enabled():
-            raise _lib.GanAmdError("LayerNorm2d: second-order derivatives are not implemented (generator-side op)")
-        xc, w32, stats, y = ctx.saved_tensors
+            # a create_graph region (WGAN-GP / R1 through DcGanDiscriminator(norm="layer")): nn.LayerNorm over the channel
+            # axis out of differentiable library ops, as the reference runs it (modelling/common.py:19-24)
+            with torch.enable_grad():
+                c = x_in.shape[1]
+                z = torch.nn.functional.layer_norm(x_in.float().permute(0, 2, 3, 1), (c,), w_in.float().reshape(c), b_in.float().reshape(c), ctx.eps)
+                z = z.permute(0, 3, 1, 2)
+                z = torch.nn.functional.leaky_relu(z, ctx.slope) if ctx.slope != 1.0 else z
+                wanted = [t for i, t in enumerate((x_in, w_in, b_in)) if _need(ctx, i)]
+                grads = iter(torch.autograd.grad(z, wanted, g.float(), create_graph=True, allow_unused=True))
+            return tuple(next(grads) if _need(ctx, i) else None for i in range(3)) + (None, None)
         n, c, h, w = xc.shape
         gc = as_cl(g.detach().to(xc.dtype))
         gx = torch.empty_like(xc) if _need(ctx, 0) else None

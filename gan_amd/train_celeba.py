@@ -6,7 +6,12 @@
         --optimizer Adam --optimizer_kwargs '{"betas":[0.0,0.9]}' --batch_size 64 --n_iters 100
     torchrun --nproc-per-node 8 -m gan_amd.train_celeba ... --batch_size 256     # global batch, sharded
 
-Out of scope here: the CelebA loader, wandb, PNG dumps, FID.
+Every `log_img_interval` iterations rank 0 writes the 10 x 10 grid of the fixed latents for `gen` and `gen_ema`
+(train_celeba.py:162-168) under images_celeba/<run_name>/; `checkpoint_interval` > 0 saves a resumable checkpoint there
+and `--resume PATH` continues from one.  FID (train_celeba.py:170-179) needs an Inception feature network and the CelebA
+statistics, neither of which exists in this image: `run_fid(trainer, fid_scorer, ref_stats)` is the hook a caller with
+both passes to main's loop through `fid=`; without it the interval is skipped.
+Out of scope here: the CelebA loader, wandb.
 """
 import json
 import os
@@ -63,6 +68,9 @@ class TrainConfig:
     # optimizer step + EMA update early in the next one, under work that does not read the generator (Trainer.flush()
     # settles it).  On whenever the job has more than one rank; this switch turns it on for a single rank too (tests).
     defer_g_step: bool = False
+    # checkpoints (absent in the reference): every N iterations under images_celeba/<run_name>/ (0: never); resume path
+    checkpoint_interval: int = 0
+    resume: str = ""
 
 
 def _fix_betas(kwargs: dict) -> dict:
@@ -456,7 +464,39 @@ def synthetic_reals(cfg: TrainConfig, device: torch.device, local_batch: int, se
     return next_reals
 
 
-def main(argv=None) -> None:
+def dump_samples(trainer: "Trainer", fixed_zs: Tensor, log_img_dir: str, step: int) -> List[str]:
+    """train_celeba.py:162-168: the fixed latents through `gen` and `gen_ema`, as 10 x 10 PNG grids.  Runs outside the captured
+    graphs; a deferred generator update is settled first."""
+    from .imageio import sample_grid, write_png
+
+    trainer.flush()
+    paths = []
+    for suffix, model in (("", trainer.gen), ("_ema", trainer.gen_ema)):
+        with trainer.autocast_ctx(), torch.no_grad():
+            fakes = model(fixed_zs)
+        path = os.path.join(log_img_dir, f"step{step // 1000:04d}k{suffix}.png")
+        write_png(sample_grid(fakes), path)
+        paths.append(path)
+    GF.drop_packed()  # (packed images of the EMA weights must not outlive the next EMA update)
+    return paths
+
+
+def run_fid(trainer: "Trainer", fid_scorer, ref_stats, batch_size: int) -> float:
+    """train_celeba.py:170-179: FID of gen_ema samples against precomputed statistics (gan_amd/fid.py)."""
+    trainer.flush()
+
+    def closure():
+        zs = torch.randn(batch_size, trainer.z_dim, device=trainer.device)
+        with trainer.autocast_ctx(), torch.no_grad():
+            return trainer.gen_ema(zs).float()
+
+    stats = fid_scorer.compute_stats(closure)
+    GF.drop_packed()
+    return float(fid_scorer.fid_score(ref_stats, stats))
+
+
+def main(argv=None, fid=None) -> None:
+    """fid: optional (fid_scorer, reference_stats) pair (gan_amd.fid.FID with a feature network, and the data set's statistics)."""
     args = make_parser(TrainConfig).parse_args(argv)
     cfg = TrainConfig(**vars(args))
     rank, world, device = init_from_env(cfg.device)
@@ -469,18 +509,37 @@ def main(argv=None) -> None:
     local_batch = cfg.batch_size // world // cfg.grad_accum
     torch.manual_seed(1234 + rank)
     trainer = Trainer(cfg, device, world)
+    if cfg.resume:
+        trainer.load_checkpoint(cfg.resume)
+    fixed_zs = torch.randn(100, trainer.z_dim, device=device, generator=torch.Generator(device=device).manual_seed(2024))
+    log_img_dir = os.path.join("images_celeba", cfg.run_name)
+    if rank == 0:
+        os.makedirs(log_img_dir, exist_ok=True)
     next_reals = synthetic_reals(cfg, device, local_batch, seed=0, rank=rank, world=world)
     t0 = time.perf_counter()
     while trainer.step < cfg.n_iters:
         logs = trainer.train_step(next_reals)
-        if trainer.step % 50 == 0 and rank == 0:
+        step = trainer.step
+        if step % 50 == 0 and rank == 0:
             if device.type == "cuda":
                 torch.cuda.synchronize()
             dt = time.perf_counter() - t0
             rec = {k: float(v) if v.numel() == 1 else v.tolist() for k, v in logs.items()}
-            rec.update(step=trainer.step, img_per_s=50 * cfg.batch_size / dt)
+            rec.update(step=step, img_per_s=50 * cfg.batch_size / dt)
             print(json.dumps(rec), flush=True)
             t0 = time.perf_counter()
+        if cfg.log_img_interval > 0 and step % cfg.log_img_interval == 0:
+            trainer.flush()  # (every rank: the flush ends a collective)
+            if rank == 0:
+                dump_samples(trainer, fixed_zs, log_img_dir, step)
+        if fid is not None and cfg.fid_interval > 0 and step % cfg.fid_interval == 0:
+            score = run_fid(trainer, fid[0], fid[1], cfg.batch_size)
+            if rank == 0:
+                print(json.dumps({"step": step, "fid/ema": score}), flush=True)
+        if cfg.checkpoint_interval > 0 and step % cfg.checkpoint_interval == 0:
+            trainer.flush()
+            if rank == 0:
+                trainer.save_checkpoint(os.path.join(log_img_dir, f"step{step:07d}.pt"))
     trainer.flush()
 
 

@@ -1388,3 +1388,103 @@ def test_mapping_network_kernels(dev, n, depth):
     wts = [torch.randn_like(p_) for p_ in parts]
     (gx,) = torch.autograd.grad(sum((p_ * w_).sum() for p_, w_ in zip(parts[:-1], wts[:-1])), x)  # the last part unused: a None gradient
     assert torch.equal(gx, torch.cat(wts[:-1] + [torch.zeros_like(wts[-1])], dim=1))
+
+
+def test_norm_layers_second_order_fallback(dev):
+    """LayerNorm2d / AdaIN inside a create_graph region (a gradient penalty through DcGanDiscriminator(norm="layer"),
+    common.py:19-33): the kernels serve the first order, the backward under create_graph is the same map out of
+    differentiable library ops.  First order (kernel) and the gradient of a gradient penalty against fp64 modules."""
+    from gan_amd.modelling.common import AdaIN, LayerNorm2d
+
+    torch.manual_seed(31)
+    x = torch.randn(3, 16, 8, 8, device=dev)
+    # ---- LayerNorm2d + LeakyReLU
+    ln = LayerNorm2d(16).to(dev)
+    with torch.no_grad():
+        ln.weight.copy_(torch.randn(16) * 0.5 + 1)
+        ln.bias.copy_(torch.randn(16) * 0.2)
+    ref = torch.nn.LayerNorm(16).double()
+    ref.load_state_dict({k: v.detach().double().cpu() for k, v in ln.state_dict().items()})
+
+    def ref_ln(xd):
+        return torch.nn.functional.leaky_relu(ref(xd.permute(0, 2, 3, 1)).permute(0, 3, 1, 2), 0.2)
+
+    xg = x.clone().requires_grad_(True)
+    xd = x.detach().double().cpu().requires_grad_(True)
+    y, yd = ln.fused(xg, 0.2), ref_ln(xd)
+    assert rel_err(y, yd) < 1e-5
+    (g1,) = torch.autograd.grad(y.square().sum(), xg, create_graph=True)
+    (g1d,) = torch.autograd.grad(yd.square().sum(), xd, create_graph=True)
+    assert rel_err(g1, g1d) < 1e-4
+    gp = torch.autograd.grad(g1.square().sum(), [xg, ln.weight, ln.bias])
+    gpd = torch.autograd.grad(g1d.square().sum(), [xd, ref.weight, ref.bias])
+    for a, b in zip(gp, gpd):
+        assert rel_err(a, b) < 1e-4
+    # the first-order kernel path gives the same gradient as the fallback
+    y2 = ln.fused(xg, 0.2)
+    (g_k,) = torch.autograd.grad(y2.square().sum(), xg)
+    assert rel_err(g_k, g1d) < 1e-4
+    # ---- AdaIN + LeakyReLU
+    ad = AdaIN(16, 12).to(dev)
+    wv = torch.randn(3, 12, device=dev)
+    adr = torch.nn.ModuleDict({"w": torch.nn.Linear(12, 16), "b": torch.nn.Linear(12, 16)}).double()
+    adr["w"].load_state_dict({k: v.detach().double().cpu() for k, v in ad.style_w.state_dict().items()})
+    adr["b"].load_state_dict({k: v.detach().double().cpu() for k, v in ad.style_b.state_dict().items()})
+
+    def ref_ad(xd, wd):
+        z = torch.nn.functional.instance_norm(xd) * (adr["w"](wd) + 1)[:, :, None, None] + adr["b"](wd)[:, :, None, None]
+        return torch.nn.functional.leaky_relu(z, 0.2)
+
+    wd = wv.double().cpu()
+    y, yd = ad.fused(xg, wv, 0.2), ref_ad(xd, wd)
+    assert rel_err(y, yd) < 1e-5
+    (g1,) = torch.autograd.grad(y.square().sum(), xg, create_graph=True)
+    (g1d,) = torch.autograd.grad(yd.square().sum(), xd, create_graph=True)
+    assert rel_err(g1, g1d) < 1e-4
+    gp = torch.autograd.grad(g1.square().sum(), [xg, ad.style_w.weight, ad.style_b.bias])
+    gpd = torch.autograd.grad(g1d.square().sum(), [xd, adr["w"].weight, adr["b"].bias])
+    for a, b in zip(gp, gpd):
+        assert rel_err(a, b) < 1e-4
+
+
+def test_spectral_norm_conv_and_trainer(dev):
+    """prepare_model(spectral_norm=True) (utils.py:40-48 -- the SAGAN-style recipes): torch's spectral-norm parametrisation
+    over the HIP convolution.  One training-mode forward / backward of a parametrised gan_amd Conv2d against the same
+    parametrisation over nn.Conv2d in fp64 (output, gradient of the original weight, the power-iteration vectors), then
+    a DCGAN trainer with both networks normalised steps with finite losses and moving parameters."""
+    import copy
+
+    from gan_amd.modelling.common import Conv2d
+    from gan_amd.train_celeba import TrainConfig, Trainer
+    from gan_amd.utils import apply_spectral_norm
+
+    torch.manual_seed(41)
+    conv = Conv2d(16, 24, 3, 1, 1).to(dev)
+    ref = torch.nn.Conv2d(16, 24, 3, 1, 1).double()
+    ref.load_state_dict({k: v.detach().double().cpu() for k, v in conv.state_dict().items()})
+    apply_spectral_norm(conv)
+    apply_spectral_norm(ref)
+    pz, pr = conv.parametrizations.weight[0], ref.parametrizations.weight[0]
+    with torch.no_grad():  # the same power-iteration state on both sides
+        pr._u.copy_(pz._u.double().cpu())
+        pr._v.copy_(pz._v.double().cpu())
+    x = torch.randn(4, 16, 12, 12, device=dev)
+    xd = x.double().cpu()
+    y, yd = conv(x), ref(xd)
+    assert rel_err(y, yd) < 1e-5
+    y.square().sum().backward()
+    yd.square().sum().backward()
+    assert rel_err(conv.parametrizations.weight.original.grad, ref.parametrizations.weight.original.grad) < 1e-4
+    assert rel_err(conv.bias.grad, ref.bias.grad) < 1e-4
+    assert rel_err(pz._u, pr._u) < 1e-5 and rel_err(pz._v, pr._v) < 1e-5
+
+    cfg = TrainConfig(model="dcgan", img_size=64, disc_kwargs={"norm": "none"}, method="hinge", sn_disc=True, sn_gen=True, batch_size=8, lr=2e-4,
+                      optimizer="Adam", optimizer_kwargs={"betas": [0.0, 0.9]}, device="cuda")
+    tr = Trainer(cfg, dev)
+    before = copy.deepcopy({k: v.detach().clone() for k, v in tr.disc.state_dict().items()})
+    reals = torch.randn(8, 3, 64, 64, device=dev)
+    for _ in range(2):
+        logs = tr.train_step(lambda: reals.clone())
+    assert all(bool(torch.isfinite(v).all()) for v in logs.values())
+    moved = [k for k, v in tr.disc.state_dict().items() if v.is_floating_point() and not torch.equal(v, before[k])]
+    assert any("original" in k for k in moved), moved
