@@ -7,11 +7,17 @@ op = sys.argv[1]
 n, cin, h, w, cout, k = map(int, sys.argv[2:8])
 iters = int(sys.argv[8]) if len(sys.argv) > 8 else 10
 dev = torch.device('cuda:0')
-x = torch.randn(n, cin, h, w, device=dev).bfloat16().contiguous(memory_format=torch.channels_last)
-gy = torch.randn(n, cout, h, w, device=dev).bfloat16().contiguous(memory_format=torch.channels_last)
+# GAN_BENCH_ROTATE=R: R sets of operands used in turn, so that a launch finds its inputs in HBM as it does inside the train
+# step (one set stays in the 256 MB infinity cache between launches and flatters every kernel)
+rot = int(os.environ.get("GAN_BENCH_ROTATE", "1"))
+xs = [torch.randn(n, cin, h, w, device=dev).bfloat16().contiguous(memory_format=torch.channels_last) for _ in range(rot)]
+gys = [torch.randn(n, cout, h, w, device=dev).bfloat16().contiguous(memory_format=torch.channels_last) for _ in range(rot)]
 wgt = torch.randn(cout, cin, k, k, device=dev) / (cin * k * k) ** 0.5
 pad = (k - 1) // 2
+turn = [0]
 def run():
+    turn[0] += 1
+    x, gy = xs[turn[0] % rot], gys[turn[0] % rot]
     if op == 'wgrad':
         return GF.raw_conv2d_wgrad(x, gy, k, k, pad, pad)
     if op == 'fwd':
