@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GAN_AMD_LIB") or os.path.join(_HERE, "libgan_amd.so")
 
 GAN_F32, GAN_BF16 = 0, 1
-ABI_VERSION = 23
+ABI_VERSION = 24
 
 _SIGNATURES = {
     "gan_amd_version": (c_int, []),
@@ -83,6 +83,8 @@ _SIGNATURES = {
     "gan_rgb_conv1x1_wgrad_workspace": (c_int64, [c_int, c_int]),
     "gan_rgb_conv1x1_wgrad": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int64, c_int64, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int64] + [c_int] * 5 + [c_void_p]),
     "gan_ema_lerp": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_void_p]),
+    "gan_conv2d_fwd_dot_supported": (c_int, [c_int] * 14),
+    "gan_conv2d_fwd_dot": (c_int, [c_void_p] * 6 + [c_int] * 13 + [c_float, c_int, c_void_p]),
     "gan_scale_rows": (c_int, [c_void_p] * 5 + [c_int, c_int64, c_void_p]),
     "gan_scale_rows_bwd": (c_int, [c_void_p] * 5 + [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int64, c_void_p]),
     "gan_adam_step": (c_int, [c_void_p] * 4 + [c_int64, c_void_p, c_int] + [c_float] * 5 + [c_int, c_void_p]),

@@ -134,6 +134,9 @@ struct ConvFuse {
     const void* resid;  // nullptr, or a tensor shaped like y added to the result last (a second gradient path)
     float* ws;          // optional caller workspace (gan_conv2d_fwd_ws): lets small-grid wide layers split K
     int64_t ws_floats;
+    // gan_conv2d_fwd_dot (thin kernel only): dot_out[n][co] += sum over pixels of (result before out_scale) * dot_x[n][pixel][co]
+    const void* dot_x;
+    float* dot_out;
 };
 
 // conv_thin.hip: direct convolution for thin layers (bf16).  1 = served, 0 = shape not eligible, < 0 = error.

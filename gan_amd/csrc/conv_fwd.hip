@@ -404,7 +404,8 @@ static int conv2d_fwd_impl(const void* x, const void* wt, void* y, const float* 
                            const float* bias, const void* noise, const float* noise_scale, float slope, int N,
                            int H, int W, int Cin, int up2, int Ho, int Wo, int Cout, int kh, int kw, int py, int px,
                            int Kpad, float in_slope, int pool, const void* aux, float aux_slope, float gain, const void* resid,
-                           float* workspace, int64_t workspace_floats, int dtype, gan_stream_t stream) {
+                           float* workspace, int64_t workspace_floats, int dtype, gan_stream_t stream, const void* dot_x = nullptr,
+                           float* dot_out = nullptr) {
     GAN_CHECK_ARG(N == 0 || (x && wt && y), "conv2d_fwd: null pointer");
     GAN_CHECK_ARG(dtype == GAN_F32 || dtype == GAN_BF16, "conv2d_fwd: bad dtype %d", dtype);
     GAN_CHECK_ARG(N >= 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Ho > 0 && Wo > 0, "conv2d_fwd: bad shape");
@@ -424,6 +425,7 @@ static int conv2d_fwd_impl(const void* x, const void* wt, void* y, const float* 
     ConvArgs a;
     a.fu.in_slope = in_slope; a.fu.pool = pool; a.fu.aux = aux; a.fu.aux_slope = aux_slope; a.fu.gain = gain; a.fu.resid = resid;
     a.fu.ws = workspace; a.fu.ws_floats = workspace ? workspace_floats : 0;
+    a.fu.dot_x = dot_x; a.fu.dot_out = dot_out;
     a.x = x; a.wt = wt; a.y = y;
     a.in_scale = in_scale; a.out_scale = out_scale; a.bias = bias;
     a.noise = noise; a.noise_scale = noise_scale; a.slope = slope;
@@ -449,6 +451,10 @@ static int conv2d_fwd_impl(const void* x, const void* wt, void* y, const float* 
     const int thin = gan_conv2d_fwd_thin(x, wt, y, in_scale, out_scale, bias, noise, noise_scale, slope, N, H, W, Cin,
                                          up2, Ho, Wo, Cout, kh, kw, py, px, Kpad, a.fu, st);
     if (thin != 0) return thin < 0 ? thin : GAN_OK;
+    if (dot_out) {
+        gan_set_error("conv2d_fwd_dot: shape not served (ask gan_conv2d_fwd_dot_supported first)");
+        return GAN_ERR_ARG;
+    }
     if (!in_scale) {
         const int wide = gan_conv2d_fwd_wide(x, wt, y, out_scale, bias, noise, noise_scale, slope, N, H, W, Cin, up2, Ho, Wo,
                                              Cout, kh, kw, py, px, Kpad, a.fu, st);
@@ -479,4 +485,32 @@ extern "C" int gan_conv2d_fwd_ws(const void* x, const void* wt, void* y, const f
                                  float* workspace, int64_t workspace_floats, int dtype, gan_stream_t stream) {
     return conv2d_fwd_impl(x, wt, y, in_scale, out_scale, bias, noise, noise_scale, slope, N, H, W, Cin, up2, Ho, Wo, Cout, kh, kw, py, px, Kpad,
                            in_slope, pool, aux, aux_slope, gain, resid, workspace, workspace_floats, dtype, stream);
+}
+
+// ---- the input-gradient convolution of a modulated layer with its scale + dot pass fused (include/gan_amd.h) ------------
+extern "C" int gan_conv2d_fwd_dot_supported(int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int py, int px, int Kpad,
+                                            int pool, int dtype) {
+    // mirror of gan_conv2d_fwd_thin's shape rules for the THIN_DS / THIN_DPS modes
+    if (dtype != GAN_BF16 || N <= 0) return 0;
+    if (kh != kw || (kh != 1 && kh != 3) || py != (kh - 1) / 2 || px != py) return 0;
+    if (Cin != 8 && Cin != 16 && Cin != 32 && Cin != 64) return 0;
+    if (Cout > 64 || (Cout & 3) || Wo < 32 || Ho < 8) return 0;
+    if (Kpad != (kh * kw * Cin + 31) / 32 * 32) return 0;
+    if (Ho != H + 2 * py - kh + 1 || Wo != W + 2 * px - kw + 1) return 0;
+    if (pool && ((Ho | Wo) & 1)) return 0;
+    const int64_t xb = (int64_t)N * H * W * Cin * 2;
+    const int64_t yb = (int64_t)N * (pool ? Ho / 2 : Ho) * (pool ? Wo / 2 : Wo) * Cout * 2;
+    if (xb >= (1LL << 31) || yb >= (1LL << 31) || (int64_t)N * Ho * Wo >= (1LL << 31)) return 0;
+    return 1;
+}
+
+extern "C" int gan_conv2d_fwd_dot(const void* x, const void* wt, void* y, const float* out_scale, const void* dot_x, float* dot_out, int N, int H,
+                                  int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int py, int px, int Kpad, int pool, float gain,
+                                  int dtype, gan_stream_t stream) {
+    GAN_CHECK_ARG(out_scale && dot_x && dot_out, "conv2d_fwd_dot: null pointer");
+    GAN_CHECK_ARG(gan_conv2d_fwd_dot_supported(N, H, W, Cin, Ho, Wo, Cout, kh, kw, py, px, Kpad, pool, dtype) == 1,
+                  "conv2d_fwd_dot: shape not served (thin layers only: bf16, Cin in {8, 16, 32, 64}, Cout <= 64 and a multiple of 4, >= 32 pixels wide)");
+    GAN_CHECK_ARG(((uintptr_t)y % 8) == 0 && ((uintptr_t)dot_x % 8) == 0, "conv2d_fwd_dot: y and dot_x must be 8-byte aligned");
+    return conv2d_fwd_impl(x, wt, y, nullptr, out_scale, nullptr, nullptr, nullptr, 1.f, N, H, W, Cin, 0, Ho, Wo, Cout, kh, kw, py, px, Kpad, 1.f, pool,
+                           nullptr, 1.f, gain, nullptr, nullptr, 0, dtype, stream, dot_x, dot_out);
 }

@@ -12,7 +12,12 @@ int gan_conv2d_fwd_thin(const void* x, const void* wt, void* y, const float* in_
     if (Cout > 64 || Wo < 32 || Ho < 8) return 0;
     if (Kpad != (kh * kw * Cin + 31) / 32 * 32) return 0;
     if (((uintptr_t)y % 8) != 0 || ((uintptr_t)fu.aux % 8) != 0 || ((uintptr_t)in_scale % 16) != 0) return 0;
-    const bool g_stage = in_scale || out_scale || noise;
+    if (fu.dot_out) {
+        // the modulated convolution's input gradient with its scale + dot pass on the accumulators (THIN_DS / THIN_DPS)
+        if (!fu.dot_x || !out_scale || in_scale || noise || bias || fu.aux || fu.resid || fu.in_slope != 1.f || slope != 1.f || (Cout & 3)) return 0;
+        if (((uintptr_t)fu.dot_x % 8) != 0 || ((uintptr_t)out_scale % 4) != 0 || ((uintptr_t)fu.dot_out % 4) != 0) return 0;
+    }
+    const bool g_stage = !fu.dot_out && (in_scale || out_scale || noise);
     const bool d_stage = fu.in_slope != 1.f || fu.pool || fu.aux || fu.gain != 1.f || fu.resid;
     if (g_stage && d_stage) return 0;  // no caller mixes them; the implicit-GEMM kernel takes every combination
     if (fu.pool && fu.aux) return 0;
@@ -33,7 +38,8 @@ int gan_conv2d_fwd_thin(const void* x, const void* wt, void* y, const float* in_
     a.tiles_x = a.tiles_y = 0;
     a.x_bytes = (unsigned)xb; a.y_bytes = (unsigned)yb;
     int rc;
-    if (g_stage) rc = thin_launch_g(a, Cin, kh, st);
+    if (fu.dot_out) rc = fu.pool ? thin_launch_dps(a, Cin, kh, st) : thin_launch_ds(a, Cin, kh, st);
+    else if (g_stage) rc = thin_launch_g(a, Cin, kh, st);
     else if (fu.pool && fu.resid) rc = thin_launch_dpr(a, Cin, kh, st);
     else if (fu.pool) rc = thin_launch_dp(a, Cin, kh, st);
     else if (fu.aux) rc = thin_launch_da(a, Cin, kh, st);

@@ -37,6 +37,9 @@ enum ThinMode {
     THIN_DP = 3,  // THIN_D + 2x2 average pooling of the result         (LeakyReLU -> Conv2d -> AvgPool2d, :48-50)
     THIN_DPR = 4, // THIN_DP + resid (pooled resolution) added last: the block's `shortcut + layers * scale` (:54) with the
                   // scale folded into the weights, so the residual merge costs no pass of its own
+    THIN_DS = 5,  // the modulated convolution's input gradient (stylegan2.py:29-36 backward): z = conv * gain,
+                  // dot_out[n][co] += sum_pixels z * dot_x, y = z * out_scale[n][co] -- the `scale_dot` pass on the accumulators
+    THIN_DPS = 6, // THIN_DS behind the 2x2 pooling of the result (the layer had nearest-2x upsampling in front)
 };
 
 struct ThinArgs {
@@ -60,6 +63,8 @@ int thin_launch_d(const ThinArgs& a, int Cin, int ks, hipStream_t st);
 int thin_launch_da(const ThinArgs& a, int Cin, int ks, hipStream_t st);
 int thin_launch_dp(const ThinArgs& a, int Cin, int ks, hipStream_t st);
 int thin_launch_dpr(const ThinArgs& a, int Cin, int ks, hipStream_t st);
+int thin_launch_ds(const ThinArgs& a, int Cin, int ks, hipStream_t st);
+int thin_launch_dps(const ThinArgs& a, int Cin, int ks, hipStream_t st);
 
 #ifdef THIN_MODE
 namespace {
@@ -99,7 +104,8 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) conv_thin_k(const Th
     constexpr int NT = C::NT;
     constexpr int CP = C::CP, TH = C::TH, HWD = C::HWD, NPIX = C::NPIX, PLANE = C::PLANE;
     constexpr int NSTEP = C::NSTEP, KPAD = C::KPAD, FCO = C::FCO, FPX = C::FPX, NLD = C::NLD;
-    constexpr bool G = MODE == THIN_G, AUX = MODE == THIN_DA, POOL = MODE == THIN_DP || MODE == THIN_DPR, RES = MODE == THIN_DPR;
+    constexpr bool G = MODE == THIN_G, AUX = MODE == THIN_DA, POOL = MODE == THIN_DP || MODE == THIN_DPR || MODE == THIN_DPS, RES = MODE == THIN_DPR;
+    constexpr bool DOT = MODE == THIN_DS || MODE == THIN_DPS;
 
     __shared__ __attribute__((aligned(256))) char lds[C::LDS_BYTES];
     char* const xl = lds;
@@ -129,10 +135,10 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) conv_thin_k(const Th
 
     const __amdgpu_buffer_rsrc_t rx = thin_rsrc(p.x, p.x_bytes);
     const __amdgpu_buffer_rsrc_t ry = thin_rsrc(p.y, p.y_bytes);
-    const __amdgpu_buffer_rsrc_t raux = thin_rsrc(AUX ? p.fu.aux : nullptr, p.y_bytes);
+    const __amdgpu_buffer_rsrc_t raux = thin_rsrc(AUX ? p.fu.aux : (DOT ? p.fu.dot_x : nullptr), p.y_bytes);
     const __amdgpu_buffer_rsrc_t rres = thin_rsrc((AUX || RES) ? p.fu.resid : nullptr, p.y_bytes);
     const __amdgpu_buffer_rsrc_t rnoise = thin_rsrc(G ? p.noise : nullptr, p.Cout ? p.y_bytes / (unsigned)p.Cout : 0u);
-    const __amdgpu_buffer_rsrc_t rosc = thin_rsrc(G ? p.out_scale : nullptr, (unsigned)(p.N * p.Cout) * 4u);
+    const __amdgpu_buffer_rsrc_t rosc = thin_rsrc((G || DOT) ? p.out_scale : nullptr, (unsigned)(p.N * p.Cout) * 4u);
     const __amdgpu_buffer_rsrc_t rsty = thin_rsrc(G ? p.in_scale : nullptr, (unsigned)(p.N * CIN) * 4u);
 
     const int tiles_per_img = p.tiles_x * p.tiles_y;
@@ -160,8 +166,9 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) conv_thin_k(const Th
         const int rem = t - n * tiles_per_img;
         const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
         const int ly0 = ty * TH - p.py, lx0 = tx * 32 - p.px;
-        if (G) {
+        if (G || DOT)
             osc_reg = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rosc, tid < p.Cout ? (n * p.Cout + tid) * 4 : THIN_INV, 0, 0));
+        if (G) {
             const v4u s0 = __builtin_amdgcn_raw_buffer_load_b128(rsty, (n * CIN + cch * 8) * 4, 0, 0);
             const v4u s1 = __builtin_amdgcn_raw_buffer_load_b128(rsty, (n * CIN + cch * 8 + 4) * 4, 0, 0);
             sty0 = __builtin_bit_cast(float4, s0);
@@ -172,11 +179,15 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) conv_thin_k(const Th
             const int ly = ly0 + (hyx[i] >> 16), lx = lx0 + (hyx[i] & 0xffff);
             const bool ok = hyx[i] >= 0 && (unsigned)ly < (unsigned)p.Hl && (unsigned)lx < (unsigned)p.Wl;
             const unsigned off = (unsigned)(((n * p.H + (ly >> p.up2)) * p.W + (lx >> p.up2)) * (CIN * 2) + cch * 16);
+#ifdef THIN_ABL_NOLOAD  // diagnostic build: no input traffic
+            reg[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, (ok && off == 0x7ffffff0u) ? off : THIN_INV, 0, 0);
+#else
             reg[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? off : THIN_INV, 0, 0);
+#endif
         }
     };
     auto commit = [&]() {
-        if (G && tid < COUT) pl[2 * COUT + tid] = p.out_scale ? osc_reg : 1.f;
+        if ((G || DOT) && tid < COUT) pl[2 * COUT + tid] = p.out_scale ? osc_reg : 1.f;
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             const int idx = i * NT + tid;
@@ -202,6 +213,31 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) conv_thin_k(const Th
     const char* const xlane = xl + (wave * RPW * HWD + lpx) * 16;
     const int OH = POOL ? p.Ho >> 1 : p.Ho, OW = POOL ? p.Wo >> 1 : p.Wo;
     const float gain = POOL ? 0.25f * p.fu.gain : p.fu.gain;
+
+    // THIN_DS / THIN_DPS: per-lane partial sums of z * dot_x for the lane's 4 x FCO channels, carried across the tiles of one
+    // image (a workgroup's tiles are consecutive: it meets at most a few images) and flushed -- folded over the 16 lanes that
+    // share the channels, then one fp32 atomic per channel and wave -- when the image changes and at the end
+    float dacc[DOT ? FCO : 1][4];
+#pragma unroll
+    for (int i = 0; i < (DOT ? FCO : 1); ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dacc[i][j] = 0.f;
+    int n_acc = -1;
+    auto flush_dot = [&](int nn) {
+#pragma unroll
+        for (int i = 0; i < (DOT ? FCO : 1); ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float v = dacc[i][j];
+                v += __shfl_xor(v, 1);
+                v += __shfl_xor(v, 2);
+                v += __shfl_xor(v, 4);
+                v += __shfl_xor(v, 8);
+                const int co = i * 16 + kg * 4 + j;
+                if (lpx == 0 && co < p.Cout) atomicAdd(p.fu.dot_out + (int64_t)nn * p.Cout + co, v);
+                dacc[i][j] = 0.f;
+            }
+    };
 
     // The wait for a halo and every memory instruction issued after its loads sit in the SAME iteration
     // (issue -> compute -> stores -> commit), so the compiler's count is exact; with the commit at the top
@@ -237,6 +273,9 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) conv_thin_k(const Th
 #pragma unroll
                 for (int i = 0; i < FCO; ++i) acc[i][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b, acc[i][f], 0, 0, 0);
             }
+#ifdef THIN_ABL_ONESTEP  // diagnostic build: one K step per tile (no MFMA / fragment-read phase to speak of)
+            break;
+#endif
         }
 
         // ---- epilogue: lane holds channels co0..co0+3 (co0 = 16*i + 4*kg) of one pixel per slot --------
@@ -246,8 +285,12 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) conv_thin_k(const Th
         const int rem = t - n * tiles_per_img;
         const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
         constexpr int NE = POOL ? RPW : FPX;
+        if (DOT) {
+            if (n != n_acc && n_acc >= 0) flush_dot(n_acc);  // (wave-uniform)
+            n_acc = n;
+        }
         // batches of EB slots: first the batch's per-pixel loads (noise / mask), then its stores
-        constexpr int EB = (G || AUX || RES) ? (FCO >= 4 ? 1 : (4 / FCO < NE ? 4 / FCO : NE)) : NE;
+        constexpr int EB = (G || AUX || RES || DOT) ? (FCO >= 4 ? 1 : (4 / FCO < NE ? 4 / FCO : NE)) : NE;
 #pragma unroll
         for (int e0 = 0; e0 < NE; e0 += EB) {
             float nz[EB];
@@ -288,6 +331,13 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) conv_thin_k(const Th
                     for (int i = 0; i < FCO; ++i) {
                         const int co0 = i * 16 + kg * 4;
                         rs[k][i] = __builtin_amdgcn_raw_buffer_load_b64(rres, (live && co0 < p.Cout) ? mo[k] + co0 * 2 : THIN_INV, 0, 0);
+                    }
+                }
+                if (DOT) {  // (dead slots and channels read zeros: they add nothing to the sums)
+#pragma unroll
+                    for (int i = 0; i < FCO; ++i) {
+                        const int co0 = i * 16 + kg * 4;
+                        ax[k][i] = __builtin_amdgcn_raw_buffer_load_b64(raux, (live && co0 < p.Cout) ? mo[k] + co0 * 2 : THIN_INV, 0, 0);
                     }
                 }
             }
@@ -333,11 +383,25 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) conv_thin_k(const Th
 #pragma unroll
                         for (int j = 0; j < 4; ++j) v[j] += (float)r4[j];
                     }
+                    if (DOT) {
+                        const bf16x4 a4 = __builtin_bit_cast(bf16x4, ax[k][i]);
+                        const float4 d4 = *reinterpret_cast<const float4*>(pl + 2 * COUT + co0);
+                        const float dd[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            dacc[i][j] = fmaf(v[j], (float)a4[j], dacc[i][j]);
+                            v[j] *= dd[j];
+                        }
+                    }
                     bf16x4 o;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) o[j] = (bf16)v[j];
                     if (VEC) {
+#ifdef THIN_ABL_NOSTORE  // diagnostic build: no output traffic
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, o), ry, (co0 < p.Cout && o[0] == (bf16)12345.f && o[1] == (bf16)777.f) ? mo[k] + co0 * 2 : THIN_INV, 0, 0);
+#else
                         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, o), ry, co0 < p.Cout ? mo[k] + co0 * 2 : THIN_INV, 0, 0);
+#endif
                     } else {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
@@ -353,6 +417,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) conv_thin_k(const Th
         commit();         // waits for this iteration's halo loads only: the stores above stay in flight
         __syncthreads();
     }
+    if (DOT && n_acc >= 0) flush_dot(n_acc);
 }
 
 template <int CIN, int COUT, int KS, int RPW, bool VEC, int NW = 4>
@@ -379,7 +444,8 @@ int launch_thin_v(ThinArgs a, hipStream_t st) {
 template <int CIN, int COUT, int KS, int RPW>
 int launch_thin(const ThinArgs& a, hipStream_t st) {
     if ((a.Cout & 3) == 0) return launch_thin_v<CIN, COUT, KS, RPW, true>(a, st);
-    if constexpr (COUT == 16 && THIN_MODE != THIN_DP && THIN_MODE != THIN_DPR) return launch_thin_v<CIN, COUT, KS, RPW, false>(a, st);
+    if constexpr (COUT == 16 && THIN_MODE != THIN_DP && THIN_MODE != THIN_DPR && THIN_MODE != THIN_DS && THIN_MODE != THIN_DPS)
+        return launch_thin_v<CIN, COUT, KS, RPW, false>(a, st);
     gan_set_error("conv2d_fwd(thin): Cout=%d not served", a.Cout);  // the dispatcher filters these shapes
     return GAN_ERR_ARG;
 }
@@ -402,7 +468,7 @@ int pick_cin(const ThinArgs& a, int Cin, hipStream_t st) {
             // tiles bring that to 67 KB = two per CU (their load and MFMA phases overlap).  Cout = 64 stays at 8 rows: its
             // 74 KB weight image alone pins it to one workgroup per CU either way.
             // (not the pooled mode: a wave pools the row pair it owns)
-            if constexpr (KS == 3 && THIN_MODE != THIN_DP && THIN_MODE != THIN_DPR) {
+            if constexpr (KS == 3 && THIN_MODE != THIN_DP && THIN_MODE != THIN_DPR && THIN_MODE != THIN_DPS) {
                 if (a.Cout <= 32 && getenv("GAN_AMD_THIN64_RPW2") == nullptr) return pick_cout<64, KS, 1>(a, st);
             }
             // Cout = 64, 3 x 3: the 74 KB weight image leaves one workgroup per CU -- as 4 waves that is ONE wave per SIMD (PMC:

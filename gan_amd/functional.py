@@ -20,6 +20,7 @@ these primitives.
 from __future__ import annotations
 
 import contextlib
+import os
 import weakref
 from typing import Dict, Optional, Tuple
 
@@ -822,6 +823,50 @@ def raw_conv2d(
         "gan_conv2d_fwd",
     )
     return y if cout == cout_real else y[:, :cout_real]
+
+
+_FUSE_SCALE_DOT = os.environ.get("GAN_AMD_FUSE_SD", "1") != "0"  # A/B runs: 0 = raw_conv2d + raw_scale_dot
+
+
+def raw_conv2d_dgrad_scale_dot(gz: Tensor, weight: Tensor, py: int, px: int, s: Tensor, xin: Tensor, *, pool: bool = False, gain: float = 1.0):
+    """The input gradient of a modulated convolution with the backward of its `x * s` on the accumulators (gan_conv2d_fwd_dot):
+    gxs = conv(gz, weight^T flipped, pad k-1-p) * gain [2x2-pooled], returns (gxs * s[n, c], sum_hw gxs * xin) -- or None where the
+    kernel does not serve the shape (the caller then runs raw_conv2d + raw_scale_dot).  weight: (Cout, Cin, kh, kw) of the layer."""
+    require_gpu(gz, weight, s, xin)
+    lib = _lib.load()
+    if gz.dtype != torch.bfloat16 or not _FUSE_SCALE_DOT:
+        return None
+    gz = _pad_channels(gz.detach(), 8)
+    n, cz_p, h, w = gz.shape
+    cz, cin, kh, kw = weight.shape  # the layer's (Cout, Cin): this convolution maps Cout -> Cin
+    if cin % 4 or cz_p > 64 or tuple(xin.shape[:2]) != (n, cin):
+        return None
+    ho, wo = h + 2 * py - kh + 1, w + 2 * px - kw + 1
+    hy, wy = (ho // 2, wo // 2) if pool else (ho, wo)
+    if tuple(xin.shape[2:]) != (hy, wy):
+        return None
+    kpad_guess = (kh * kw * cz_p + 31) // 32 * 32
+    if lib.gan_conv2d_fwd_dot_supported(n, h, w, cz_p, ho, wo, cin, kh, kw, py, px, kpad_guess, int(pool), dtype_code(gz)) != 1:
+        return None
+    wt, cz_p2, kpad = pack_weight(weight, gz.dtype, cin_mult=16 if cz < 8 else 8, transposed=True)
+    if cz_p2 != cz_p or kpad != kpad_guess:
+        return None
+    s32 = _f32(s).reshape(n, cin).contiguous()
+    xc = as_cl(xin.detach().to(gz.dtype))
+    y = _empty_like_cl(gz, (n, cin, hy, wy))
+    zeroed = _zeroed(n * cin, gz.device)
+    dot = zeroed.view(n, cin) if zeroed is not None else torch.zeros((n, cin), dtype=torch.float32, device=gz.device)
+    family = f"conv2d_fwd_thin<{cz_p},{16 if cin <= 16 else (32 if cin <= 32 else 64)},{kh},{'DPS' if pool else 'DS'}>"
+    check(
+        _run(
+            family, 2.0 * n * ho * wo * cin * cz * kh * kw, _nbytes(gz, y, wt, xc),
+            lambda: lib.gan_conv2d_fwd_dot(ptr(gz), ptr(wt), ptr(y), ptr(s32), ptr(xc), ptr(dot), n, h, w, cz_p, ho, wo, cin, kh, kw, py, px, kpad,
+                                           int(pool), float(gain), dtype_code(gz), stream_of(gz)),
+            (n, cz, ho, wo, cin, kh, 0, int(pool)),
+        ),
+        "gan_conv2d_fwd_dot",
+    )
+    return y, dot
 
 
 def raw_conv2d_dgrad(

@@ -104,14 +104,23 @@ class ModConvFn(Function):
         gx = gw = gs = None
         if need[0] or need[2]:
             # d/d(U(x)*s); with U = nearest x2 its adjoint (the sum of each 2x2 block) rides on the accumulators
-            gxs = GF.raw_conv2d(gz, weight, kh - 1 - pad, kh - 1 - pad, transposed=True, pool=up2, gain=4.0 if up2 else 1.0)
+            tpad = kh - 1 - pad
+            fused = None
             if need[0] and need[2]:
-                gx, gs = GF.raw_scale_dot(gxs, x, s)  # one pass: dx = gxs * s and ds = sum_hw gxs * x
+                # thin layers: dx = gxs * s and ds = sum_hw gxs * x on the convolution's accumulators (no gxs tensor)
+                fused = GF.raw_conv2d_dgrad_scale_dot(gz, weight, tpad, tpad, s, x, pool=up2, gain=4.0 if up2 else 1.0)
+            if fused is not None:
+                gx, gs = fused
                 gs = gs.reshape(s.shape).to(s.dtype)
-            elif need[2]:
-                gs = GF.raw_chan_dot(gxs, x, 1, None, 1.0, True).reshape(s.shape).to(s.dtype)
             else:
-                gx = GF.raw_mask_scale(gxs, None, s, 1.0) if s is not None else gxs
+                gxs = GF.raw_conv2d(gz, weight, tpad, tpad, transposed=True, pool=up2, gain=4.0 if up2 else 1.0)
+                if need[0] and need[2]:
+                    gx, gs = GF.raw_scale_dot(gxs, x, s)  # one pass: dx = gxs * s and ds = sum_hw gxs * x
+                    gs = gs.reshape(s.shape).to(s.dtype)
+                elif need[2]:
+                    gs = GF.raw_chan_dot(gxs, x, 1, None, 1.0, True).reshape(s.shape).to(s.dtype)
+                else:
+                    gx = GF.raw_mask_scale(gxs, None, s, 1.0) if s is not None else gxs
         if need[1]:
             slot = GF.grad_slot(weight)  # a buffer the fold kernel adds to (functional.py: direct_param_grads), or None
             gw = GF.raw_conv2d_wgrad(x, gz, kh, kh, pad, pad, up2=up2, in_scale=s, into=slot)

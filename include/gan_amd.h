@@ -349,6 +349,22 @@ int gan_layernorm2d_fwd(const void* x, const float* w, const float* b, void* y, 
 int gan_layernorm2d_bwd(const void* g, const void* x, const void* ymask, const float* w, const float* stats, void* gx, float* gwb,
                         int64_t NP, int C, float slope, int dtype, gan_stream_t stream);
 
+/* ---- input gradient of a modulated convolution with its scale + dot pass on the accumulators ----
+ * replaces the backward of `x * style` in front of the shared-weight convolution              modelling/stylegan2.py:30-35
+ * With gxs = conv(gz, W^T flipped) * gain [2x2-pooled: the adjoint of the layer's nearest-2x upsampling], autograd needs
+ *   gx[n][p][c] = gxs[n][p][c] * s[n][c]          (the input gradient)
+ *   gs[n][c]    = sum_p gxs[n][p][c] * xin[n][p][c]   (the style gradient; xin = the layer's saved input)
+ * i.e. a second pass that reads gxs and xin and writes gx (gan_scale_dot).  Here both ride on the convolution's
+ * accumulators: y = gx, dot_out += gs (fp32 atomics, one per channel, wave and image: dot_out must hold zeros -- or a
+ * running sum -- on entry).  x = gz (N, H, W, Cin), wt = the packed transposed / flipped weights (gan_pack_weight),
+ * out_scale = s (N, Cout) fp32, dot_x = xin shaped like y.  Thin layers only (the layers whose activations are large):
+ * gan_conv2d_fwd_dot_supported(...) == 1, else call gan_conv2d_fwd and gan_scale_dot. */
+int gan_conv2d_fwd_dot_supported(int N, int H, int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int py, int px, int Kpad, int pool,
+                                 int dtype);
+int gan_conv2d_fwd_dot(const void* x, const void* wt, void* y, const float* out_scale, const void* dot_x, float* dot_out, int N, int H, int W,
+                       int Cin, int Ho, int Wo, int Cout, int kh, int kw, int py, int px, int Kpad, int pool, float gain, int dtype,
+                       gan_stream_t stream);
+
 /* ---- convolution parameters scaled per output channel ------------------------------------
  * replaces the activation-sized multiply of `self.shortcut(x) + self.layers(x) * self.scale`   modelling/progressive_gan.py:54
  * conv(x, W) * scale + b * scale = conv(x, W * scale) + b * scale: the block's last convolution runs on

@@ -1488,3 +1488,46 @@ def test_spectral_norm_conv_and_trainer(dev):
     assert all(bool(torch.isfinite(v).all()) for v in logs.values())
     moved = [k for k, v in tr.disc.state_dict().items() if v.is_floating_point() and not torch.equal(v, before[k])]
     assert any("original" in k for k in moved), moved
+
+
+@pytest.mark.parametrize("case", [
+    # (N, layer Cout = channels of gz, layer Cin = channels of the result, H, W of gz, k, pooled)
+    (3, 16, 16, 64, 64, 3, False), (2, 32, 16, 40, 64, 3, False), (5, 16, 32, 64, 96, 3, True), (2, 64, 64, 32, 32, 3, False),
+    (2, 64, 32, 64, 64, 3, True), (3, 3, 16, 48, 64, 1, False), (40, 16, 16, 32, 32, 3, False), (2, 32, 64, 64, 64, 3, True),
+])
+def test_conv2d_dgrad_scale_dot(dev, case):
+    """gan_conv2d_fwd_dot: the modulated convolution's input gradient with the backward of `x * s` (stylegan2.py:30-35) on its
+    accumulators -- gx = gxs * s and gs = sum_hw gxs * x -- against fp64 (conv_transpose2d, 2x2 block sum under the layer's
+    upsampling) and against the two-pass path it replaces; ragged tiles, several images per workgroup (the per-image flush),
+    the sums taken from the zeroed pool of a trainer's backward pass."""
+    import gan_amd.functional as GF
+
+    n, cz, cin, h, w, k, pooled = case
+    torch.manual_seed(sum(case))
+    pad = (k - 1) // 2
+    gz = torch.randn(n, cz, h, w, device=dev).bfloat16().contiguous(memory_format=torch.channels_last)
+    weight = (torch.randn(cz, cin, k, k, device=dev) / (cz * k * k) ** 0.5)
+    s = torch.randn(n, cin, device=dev) * 0.5 + 1.0
+    hy, wy = (h // 2, w // 2) if pooled else (h, w)
+    xin = torch.randn(n, cin, hy, wy, device=dev).bfloat16().contiguous(memory_format=torch.channels_last)
+    tpad = k - 1 - pad
+    got = GF.raw_conv2d_dgrad_scale_dot(gz, weight, tpad, tpad, s, xin, pool=pooled, gain=4.0 if pooled else 1.0)
+    assert got is not None, "shape not served by the fused kernel"
+    gx, gs = got
+    w64 = weight.bfloat16().double()  # (the kernel multiplies bf16 weights)
+    gxs = F.conv_transpose2d(gz.double(), w64, padding=pad)
+    if pooled:
+        gxs = 4.0 * F.avg_pool2d(gxs, 2)
+    want_gx = gxs * s.double()[:, :, None, None]
+    want_gs = (gxs * xin.double()).sum(dim=(2, 3))
+    assert gx.shape == want_gx.shape and gx.dtype == torch.bfloat16
+    assert rel_err(gx, want_gx) < 6e-3
+    assert rel_err(gs, want_gs) < 2e-3, rel_err(gs, want_gs)
+    # the path it replaces
+    gxs2 = GF.raw_conv2d(gz, weight, tpad, tpad, transposed=True, pool=pooled, gain=4.0 if pooled else 1.0)
+    gx2, gs2 = GF.raw_scale_dot(gxs2, xin, s)
+    assert rel_err(gx, gx2) < 1e-2 and rel_err(gs, gs2) < 1e-2
+    # inside a zeroed-scratch region the sums come from the pool (a trainer's backward pass)
+    with GF.zeroed_scratch(dev):
+        gx3, gs3 = GF.raw_conv2d_dgrad_scale_dot(gz, weight, tpad, tpad, s, xin, pool=pooled, gain=4.0 if pooled else 1.0)
+        assert torch.equal(gx3, gx) and rel_err(gs3, want_gs) < 2e-3
