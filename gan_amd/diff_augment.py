@@ -15,9 +15,9 @@ from __future__ import annotations
 
 import torch
 from torch import Tensor, nn
-from torch.autograd import Function
 
 from . import _lib
+from .functional import Function
 from ._lib import check, dtype_code, ptr, require_gpu, stream_of
 
 def rand_int(lo: int, hi: int) -> int:

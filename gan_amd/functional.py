@@ -27,7 +27,7 @@ from typing import Dict, Optional, Tuple
 import torch
 import torch.nn.functional as F
 from torch import Tensor
-from torch.autograd import Function
+from torch.autograd import Function as _TorchFunction
 
 from . import _lib
 from ._lib import check, dtype_code, ptr, require_gpu, stream_of
@@ -969,8 +969,49 @@ def raw_ema_lerp(ema_flat: Tensor, p_flat: Tensor, weight: float) -> None:
 # ======================================================================================
 # differentiable primitives
 # ======================================================================================
+class Function(_TorchFunction):
+    """torch.autograd.Function whose node remembers which positional arguments were tensors: the node's gradient edges
+    (`next_functions`) are numbered over the tensor arguments only, `needs_input_grad` over all of them (see _need)."""
+
+    @classmethod
+    def apply(cls, *args, **kwargs):
+        out = super().apply(*args, **kwargs)
+        first = out if isinstance(out, Tensor) else next((o for o in out if isinstance(o, Tensor)), None) if isinstance(out, (tuple, list)) else None
+        node = getattr(first, "grad_fn", None)
+        if node is not None and isinstance(node, cls._backward_cls):
+            pos, k = [], 0
+            for a in args:
+                if isinstance(a, Tensor):
+                    pos.append(k)
+                    k += 1
+                else:
+                    pos.append(-1)
+            node._gan_edge_of_arg = tuple(pos)
+        return out
+
+
 def _need(ctx, i: int) -> bool:
-    return ctx.needs_input_grad[i]
+    """Does THIS backward pass want the gradient of input i?  `ctx.needs_input_grad` is fixed at forward time (does the input
+    require grad at all): under `torch.autograd.grad(out, inputs=[reals], create_graph=True)` -- the first pass of R1 and of
+    the WGAN gradient penalty (losses.py:95-103) -- it still says True for every weight and bias, and a backward that believes
+    it computes a weight gradient and a bias sum per layer that the engine then throws away (a third of the discriminator's
+    weight-gradient kernels per iteration).  The engine knows which nodes the running graph task will execute: an input whose
+    gradient edge leads to a node it will not execute is not wanted."""
+    if not ctx.needs_input_grad[i]:
+        return False
+    if not _PRUNE_UNWANTED:
+        return True
+    edge = getattr(ctx, "_gan_edge_of_arg", None)
+    if edge is None or i >= len(edge) or edge[i] < 0:
+        return True
+    try:
+        fn = ctx.next_functions[edge[i]][0]
+        return True if fn is None else bool(torch._C._will_engine_execute_node(fn))
+    except Exception:  # (leaf nodes under autograd.grad raise: those are asked for by name; anything unexpected: compute)
+        return True
+
+
+_PRUNE_UNWANTED = os.environ.get("GAN_AMD_PRUNE_GRADS", "1") != "0" and hasattr(torch._C, "_will_engine_execute_node")  # A/B runs: 0
 
 
 # ---- parameter gradients added into their buffers by the kernels that compute them -------------------------

@@ -23,9 +23,9 @@ from typing import Optional
 import torch
 import torch.nn.functional as F
 from torch import Tensor, nn
-from torch.autograd import Function
 
 from .. import functional as GF
+from ..functional import Function
 from .common import LeakyReLU, Upsample, to_act
 from .progressive_gan import init_weights
 from .stylegan import Noise
