@@ -119,6 +119,7 @@ class Trainer:
         self.optim_g = make_optimizer(cfg.optimizer, self.gen, cfg.lr, okw, capturable=cfg.hip_graph)
         self.autocast_ctx = lambda: torch.autocast(self.device.type, dtype=torch.bfloat16, enabled=cfg.mixed_precision)
         self.step = 0
+        self._d_params = [p for p in self.disc.parameters() if p.requires_grad]
         self._conv_w_g = [p for p in self.gen.parameters() if p.dim() == 4]
         self._conv_w_d = [p for p in self.disc.parameters() if p.dim() == 4]
 
@@ -384,7 +385,9 @@ class Trainer:
                     self.red_d.arena.begin_direct()
                 d_losses.append(loss_d.detach())
                 with GF.direct_param_grads(not overlap):  # (the hook-driven exchange needs autograd's accumulation step)
-                    loss_d.backward()
+                    # inputs = the parameters: `reals` requires grad for the regularizer (train_celeba.py:121), and a plain
+                    # backward() would also carry both gradient paths all the way into the image (reals.grad, which nobody reads)
+                    loss_d.backward(inputs=self._d_params)
                 if last:
                     if overlap:
                         self.red_d.finish()
