@@ -210,3 +210,35 @@ def test_grad_bucket_reducer_gloo_world2(tmp_path):
     assert rel_err(got, ref) < 1e-6  # mean of shard gradients == full-batch gradient
     tail = torch.cat([g0[o : o + n] for o, n in layout[n_model:]])
     assert float(tail.abs().max()) == 0.0
+
+
+def test_need_follows_the_running_autograd_task():
+    """functional._need: `ctx.needs_input_grad` says whether an input requires grad at all; which gradients THIS backward
+    pass uses is the engine's knowledge.  Under autograd.grad(out, inputs=[x]) -- the first pass of R1 / WGAN-GP
+    (losses.py:95-103) -- a weight's gradient is not wanted; under backward() and when the weight is asked for it is.
+    Argument positions are mapped to gradient edges (non-tensor arguments have none)."""
+    import gan_amd.functional as GF
+
+    seen = []
+
+    class Toy(GF.Function):
+        @staticmethod
+        def forward(ctx, x, k, w, b=None):
+            ctx.save_for_backward(x, w)
+            return x * w * k
+
+        @staticmethod
+        def backward(ctx, g):
+            seen.append([GF._need(ctx, i) for i in range(4)])
+            x, w = ctx.saved_tensors
+            return g * w, None, g * x, None
+
+    x0 = torch.randn(3, requires_grad=True)
+    w = torch.randn(3, requires_grad=True)
+    torch.autograd.grad(Toy.apply(x0 * 2, 2.0, w, None).sum(), x0, create_graph=True)
+    Toy.apply(x0 * 2, 2.0, w, None).sum().backward()
+    torch.autograd.grad(Toy.apply(x0 * 2, 2.0, w, None).sum(), [x0, w])
+    torch.autograd.grad(Toy.apply(x0 * 2, 2.0, w, None).sum(), [w])
+    Toy.apply(x0 * 2, 2.0, w, None).sum().backward(inputs=[w])
+    assert seen == [[True, False, False, False], [True, False, True, False], [True, False, True, False], [False, False, True, False],
+                    [False, False, True, False]]
