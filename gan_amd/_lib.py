@@ -85,6 +85,8 @@ _SIGNATURES = {
     "gan_ema_lerp": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_void_p]),
     "gan_conv2d_fwd_dot_supported": (c_int, [c_int] * 14),
     "gan_conv2d_fwd_dot": (c_int, [c_void_p] * 6 + [c_int] * 13 + [c_float, c_int, c_void_p]),
+    "gan_conv2d_fwd_short_supported": (c_int, [c_int] * 12),
+    "gan_conv2d_fwd_short": (c_int, [c_void_p] * 4 + [c_float, c_float, c_void_p, c_void_p, c_int, c_float] + [c_int] * 11 + [c_void_p]),
     "gan_scale_rows": (c_int, [c_void_p] * 5 + [c_int, c_int64, c_void_p]),
     "gan_scale_rows_bwd": (c_int, [c_void_p] * 5 + [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int64, c_void_p]),
     "gan_adam_step": (c_int, [c_void_p] * 4 + [c_int64, c_void_p, c_int] + [c_float] * 5 + [c_int, c_void_p]),

@@ -137,6 +137,12 @@ struct ConvFuse {
     // gan_conv2d_fwd_dot (thin kernel only): dot_out[n][co] += sum over pixels of (result before out_scale) * dot_x[n][pixel][co]
     const void* dot_x;
     float* dot_out;
+    // gan_conv2d_fwd_short (thin kernel only, with aux): the residual is formed in the kernel instead of read --
+    // + sc_gain * NearestUp2( conv1x1(sc_x, sc_w) ), sc_x (N, Ho/2, Wo/2, sc_c) channels-last, sc_w packed [Cout][sc_c]
+    const void* sc_x;
+    const void* sc_w;
+    int sc_c;
+    float sc_gain;
 };
 
 // conv_thin.hip: direct convolution for thin layers (bf16).  1 = served, 0 = shape not eligible, < 0 = error.

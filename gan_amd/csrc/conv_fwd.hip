@@ -405,7 +405,7 @@ static int conv2d_fwd_impl(const void* x, const void* wt, void* y, const float* 
                            int H, int W, int Cin, int up2, int Ho, int Wo, int Cout, int kh, int kw, int py, int px,
                            int Kpad, float in_slope, int pool, const void* aux, float aux_slope, float gain, const void* resid,
                            float* workspace, int64_t workspace_floats, int dtype, gan_stream_t stream, const void* dot_x = nullptr,
-                           float* dot_out = nullptr) {
+                           float* dot_out = nullptr, const void* sc_x = nullptr, const void* sc_w = nullptr, int sc_c = 0, float sc_gain = 0.f) {
     GAN_CHECK_ARG(N == 0 || (x && wt && y), "conv2d_fwd: null pointer");
     GAN_CHECK_ARG(dtype == GAN_F32 || dtype == GAN_BF16, "conv2d_fwd: bad dtype %d", dtype);
     GAN_CHECK_ARG(N >= 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Ho > 0 && Wo > 0, "conv2d_fwd: bad shape");
@@ -426,6 +426,7 @@ static int conv2d_fwd_impl(const void* x, const void* wt, void* y, const float* 
     a.fu.in_slope = in_slope; a.fu.pool = pool; a.fu.aux = aux; a.fu.aux_slope = aux_slope; a.fu.gain = gain; a.fu.resid = resid;
     a.fu.ws = workspace; a.fu.ws_floats = workspace ? workspace_floats : 0;
     a.fu.dot_x = dot_x; a.fu.dot_out = dot_out;
+    a.fu.sc_x = sc_x; a.fu.sc_w = sc_w; a.fu.sc_c = sc_c; a.fu.sc_gain = sc_gain;
     a.x = x; a.wt = wt; a.y = y;
     a.in_scale = in_scale; a.out_scale = out_scale; a.bias = bias;
     a.noise = noise; a.noise_scale = noise_scale; a.slope = slope;
@@ -451,8 +452,8 @@ static int conv2d_fwd_impl(const void* x, const void* wt, void* y, const float* 
     const int thin = gan_conv2d_fwd_thin(x, wt, y, in_scale, out_scale, bias, noise, noise_scale, slope, N, H, W, Cin,
                                          up2, Ho, Wo, Cout, kh, kw, py, px, Kpad, a.fu, st);
     if (thin != 0) return thin < 0 ? thin : GAN_OK;
-    if (dot_out) {
-        gan_set_error("conv2d_fwd_dot: shape not served (ask gan_conv2d_fwd_dot_supported first)");
+    if (dot_out || sc_x) {
+        gan_set_error("conv2d_fwd_dot / conv2d_fwd_short: shape not served (ask gan_conv2d_fwd_dot_supported / _short_supported first)");
         return GAN_ERR_ARG;
     }
     if (!in_scale) {
@@ -513,4 +514,28 @@ extern "C" int gan_conv2d_fwd_dot(const void* x, const void* wt, void* y, const 
     GAN_CHECK_ARG(((uintptr_t)y % 8) == 0 && ((uintptr_t)dot_x % 8) == 0, "conv2d_fwd_dot: y and dot_x must be 8-byte aligned");
     return conv2d_fwd_impl(x, wt, y, nullptr, out_scale, nullptr, nullptr, nullptr, 1.f, N, H, W, Cin, 0, Ho, Wo, Cout, kh, kw, py, px, Kpad, 1.f, pool,
                            nullptr, 1.f, gain, nullptr, nullptr, 0, dtype, stream, dot_x, dot_out);
+}
+
+// ---- conv1's input gradient of a D block with the shortcut's input gradient formed in the kernel (include/gan_amd.h) ------
+extern "C" int gan_conv2d_fwd_short_supported(int N, int H, int W, int Cin, int Cout, int kh, int kw, int py, int px, int Kpad, int sc_c, int dtype) {
+    if (dtype != GAN_BF16 || N <= 0) return 0;
+    if (kh != 3 || kw != 3 || py != 1 || px != 1) return 0;
+    if (Cin != 8 && Cin != 16 && Cin != 32 && Cin != 64) return 0;
+    if ((Cout != 16 && Cout != 32) || sc_c != 2 * Cout || W < 32 || H < 8 || (H & 1) || (W & 1)) return 0;
+    if (Kpad != (9 * Cin + 31) / 32 * 32) return 0;
+    const int64_t big = (int64_t)N * H * W * (Cin > Cout ? Cin : Cout) * 2;
+    if (big >= (1LL << 31) || (int64_t)N * H * W >= (1LL << 31)) return 0;
+    return 1;
+}
+
+extern "C" int gan_conv2d_fwd_short(const void* x, const void* wt, void* y, const void* aux, float aux_slope, float gain, const void* sc_x,
+                                    const void* sc_w, int sc_c, float sc_gain, int N, int H, int W, int Cin, int Cout, int kh, int kw, int py,
+                                    int px, int Kpad, int dtype, gan_stream_t stream) {
+    GAN_CHECK_ARG(aux && sc_x && sc_w, "conv2d_fwd_short: null pointer");
+    GAN_CHECK_ARG(gan_conv2d_fwd_short_supported(N, H, W, Cin, Cout, kh, kw, py, px, Kpad, sc_c, dtype) == 1,
+                  "conv2d_fwd_short: shape not served (bf16, 3 x 3, Cout 16 or 32, sc_c = 2 Cout, even maps >= 32 pixels wide)");
+    GAN_CHECK_ARG(((uintptr_t)y % 8) == 0 && ((uintptr_t)aux % 8) == 0 && ((uintptr_t)sc_x % 16) == 0 && ((uintptr_t)sc_w % 16) == 0,
+                  "conv2d_fwd_short: y / aux must be 8-byte, sc_x / sc_w 16-byte aligned");
+    return conv2d_fwd_impl(x, wt, y, nullptr, nullptr, nullptr, nullptr, nullptr, 1.f, N, H, W, Cin, 0, H, W, Cout, kh, kw, py, px, Kpad, 1.f, 0, aux,
+                           aux_slope, gain, nullptr, nullptr, 0, dtype, stream, nullptr, nullptr, sc_x, sc_w, sc_c, sc_gain);
 }

@@ -17,6 +17,13 @@ int gan_conv2d_fwd_thin(const void* x, const void* wt, void* y, const float* in_
         if (!fu.dot_x || !out_scale || in_scale || noise || bias || fu.aux || fu.resid || fu.in_slope != 1.f || slope != 1.f || (Cout & 3)) return 0;
         if (((uintptr_t)fu.dot_x % 8) != 0 || ((uintptr_t)out_scale % 4) != 0 || ((uintptr_t)fu.dot_out % 4) != 0) return 0;
     }
+    if (fu.sc_x) {
+        // the D block's conv1 input gradient with the shortcut's input gradient formed in the kernel (THIN_DAS)
+        if (fu.dot_out || !fu.aux || fu.resid || fu.pool || in_scale || out_scale || noise || bias || up2 || fu.in_slope != 1.f || slope != 1.f) return 0;
+        if (kh != 3 || (Cout != 16 && Cout != 32) || fu.sc_c != 2 * Cout || !fu.sc_w || (Ho & 1) || (Wo & 1)) return 0;
+        if (((uintptr_t)fu.sc_x % 16) != 0 || ((uintptr_t)fu.sc_w % 16) != 0) return 0;
+        if ((int64_t)N * (Ho / 2) * (Wo / 2) * fu.sc_c * 2 >= (1LL << 31)) return 0;
+    }
     const bool g_stage = !fu.dot_out && (in_scale || out_scale || noise);
     const bool d_stage = fu.in_slope != 1.f || fu.pool || fu.aux || fu.gain != 1.f || fu.resid;
     if (g_stage && d_stage) return 0;  // no caller mixes them; the implicit-GEMM kernel takes every combination
@@ -37,8 +44,10 @@ int gan_conv2d_fwd_thin(const void* x, const void* wt, void* y, const float* in_
     a.Ho = Ho; a.Wo = Wo; a.Cout = Cout; a.py = py; a.px = px; a.Kpad = Kpad;
     a.tiles_x = a.tiles_y = 0;
     a.x_bytes = (unsigned)xb; a.y_bytes = (unsigned)yb;
+    a.sc_bytes = fu.sc_x ? (unsigned)((int64_t)N * (Ho / 2) * (Wo / 2) * fu.sc_c * 2) : 0u;
     int rc;
     if (fu.dot_out) rc = fu.pool ? thin_launch_dps(a, Cin, kh, st) : thin_launch_ds(a, Cin, kh, st);
+    else if (fu.sc_x) rc = thin_launch_das(a, Cin, kh, st);
     else if (g_stage) rc = thin_launch_g(a, Cin, kh, st);
     else if (fu.pool && fu.resid) rc = thin_launch_dpr(a, Cin, kh, st);
     else if (fu.pool) rc = thin_launch_dp(a, Cin, kh, st);

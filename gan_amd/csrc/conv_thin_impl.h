@@ -40,6 +40,10 @@ enum ThinMode {
     THIN_DS = 5,  // the modulated convolution's input gradient (stylegan2.py:29-36 backward): z = conv * gain,
                   // dot_out[n][co] += sum_pixels z * dot_x, y = z * out_scale[n][co] -- the `scale_dot` pass on the accumulators
     THIN_DPS = 6, // THIN_DS behind the 2x2 pooling of the result (the layer had nearest-2x upsampling in front)
+    THIN_DAS = 7, // THIN_DA whose residual is computed here: + sc_gain * NearestUp2( conv1x1(sc_x, sc_w) ), sc_x at half
+                  // resolution with 2 * COUT channels -- the input gradient of the D block's shortcut (AvgPool2d -> Conv2d 1x1,
+                  // progressive_gan.py:52) as extra K steps of the input-gradient convolution of conv1, instead of a kernel of
+                  // its own writing a full-resolution tensor that this one reads back
 };
 
 struct ThinArgs {
@@ -55,6 +59,7 @@ struct ThinArgs {
     int N, H, W, Hl, Wl, up2, Ho, Wo, Cout, py, px, Kpad;
     int tiles_x, tiles_y;
     unsigned x_bytes, y_bytes;  // < 2^31: 32-bit buffer offsets
+    unsigned sc_bytes;          // bytes of fu.sc_x
     ConvFuse fu;
 };
 
@@ -65,6 +70,7 @@ int thin_launch_dp(const ThinArgs& a, int Cin, int ks, hipStream_t st);
 int thin_launch_dpr(const ThinArgs& a, int Cin, int ks, hipStream_t st);
 int thin_launch_ds(const ThinArgs& a, int Cin, int ks, hipStream_t st);
 int thin_launch_dps(const ThinArgs& a, int Cin, int ks, hipStream_t st);
+int thin_launch_das(const ThinArgs& a, int Cin, int ks, hipStream_t st);
 
 #ifdef THIN_MODE
 namespace {
@@ -104,10 +110,19 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) conv_thin_k(const Th
     constexpr int NT = C::NT;
     constexpr int CP = C::CP, TH = C::TH, HWD = C::HWD, NPIX = C::NPIX, PLANE = C::PLANE;
     constexpr int NSTEP = C::NSTEP, KPAD = C::KPAD, FCO = C::FCO, FPX = C::FPX, NLD = C::NLD;
-    constexpr bool G = MODE == THIN_G, AUX = MODE == THIN_DA, POOL = MODE == THIN_DP || MODE == THIN_DPR || MODE == THIN_DPS, RES = MODE == THIN_DPR;
+    constexpr bool DAS = MODE == THIN_DAS;
+    constexpr bool G = MODE == THIN_G, AUX = MODE == THIN_DA || DAS, POOL = MODE == THIN_DP || MODE == THIN_DPR || MODE == THIN_DPS, RES = MODE == THIN_DPR;
     constexpr bool DOT = MODE == THIN_DS || MODE == THIN_DPS;
 
-    __shared__ __attribute__((aligned(256))) char lds[C::LDS_BYTES];
+    // THIN_DAS: the shortcut operand's tile (TH/2 x 16 source pixels x 2 COUT channels, [8-channel chunk][pixel][8] like the
+    // halo) and its weights ([k/8][co][8])
+    constexpr int SCC = 2 * COUT, CPS = SCC / 8, SPIX = (TH / 2) * 16, SPLANE = SPIX * 16;
+    constexpr int S_BYTES = DAS ? CPS * SPLANE : 0, SW_BYTES = DAS ? SCC * COUT * 2 : 0;
+    constexpr int NSL = DAS ? (SPIX * CPS + NT - 1) / NT : 1;
+    static_assert(!DAS || (SPIX % 8 == 0 && NT % (8 * CPS) == 0), "shortcut tile staging");
+    __shared__ __attribute__((aligned(256))) char lds[C::LDS_BYTES + S_BYTES + SW_BYTES];
+    char* const sl = lds + C::LDS_BYTES;
+    char* const swl = lds + C::LDS_BYTES + S_BYTES;
     char* const xl = lds;
     char* const wl = lds + C::X_BYTES;
     // per-channel epilogue vectors in LDS (ds_read: they never sit on the vector-memory counter)
@@ -127,6 +142,15 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) conv_thin_k(const Th
         if (co < p.Cout) v = *reinterpret_cast<const uint4*>(wt + (int64_t)co * p.Kpad + kc * 8);
         *reinterpret_cast<uint4*>(wl + idx * 16) = v;
     }
+    if (DAS) {
+        const bf16* __restrict__ scw = (const bf16*)p.fu.sc_w;
+        for (int idx = tid; idx < CPS * COUT; idx += NT) {
+            const int co = idx % COUT, kc = idx / COUT;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (co < p.Cout) v = *reinterpret_cast<const uint4*>(scw + (int64_t)co * SCC + kc * 8);
+            *reinterpret_cast<uint4*>(swl + idx * 16) = v;
+        }
+    }
     if (tid < COUT) {
         pl[tid] = (p.bias && tid < p.Cout) ? p.bias[tid] : 0.f;
         pl[COUT + tid] = (G && p.noise_scale && tid < p.Cout) ? p.noise_scale[tid] : 0.f;
@@ -136,7 +160,8 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) conv_thin_k(const Th
     const __amdgpu_buffer_rsrc_t rx = thin_rsrc(p.x, p.x_bytes);
     const __amdgpu_buffer_rsrc_t ry = thin_rsrc(p.y, p.y_bytes);
     const __amdgpu_buffer_rsrc_t raux = thin_rsrc(AUX ? p.fu.aux : (DOT ? p.fu.dot_x : nullptr), p.y_bytes);
-    const __amdgpu_buffer_rsrc_t rres = thin_rsrc((AUX || RES) ? p.fu.resid : nullptr, p.y_bytes);
+    const __amdgpu_buffer_rsrc_t rres = thin_rsrc(((AUX && !DAS) || RES) ? p.fu.resid : nullptr, p.y_bytes);
+    const __amdgpu_buffer_rsrc_t rsc = thin_rsrc(DAS ? p.fu.sc_x : nullptr, p.sc_bytes);
     const __amdgpu_buffer_rsrc_t rnoise = thin_rsrc(G ? p.noise : nullptr, p.Cout ? p.y_bytes / (unsigned)p.Cout : 0u);
     const __amdgpu_buffer_rsrc_t rosc = thin_rsrc((G || DOT) ? p.out_scale : nullptr, (unsigned)(p.N * p.Cout) * 4u);
     const __amdgpu_buffer_rsrc_t rsty = thin_rsrc(G ? p.in_scale : nullptr, (unsigned)(p.N * CIN) * 4u);
@@ -159,6 +184,16 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) conv_thin_k(const Th
         hyx[i] = pix < NPIX ? (hy << 16) | hx : -1;
     }
     v4u reg[NLD];
+    v4u sreg[NSL];
+    int spc[NSL];  // THIN_DAS: (pixel << 8) | chunk of shortcut-tile slot i, -1 past the tile (zeros into the dump slot)
+    if (DAS) {
+#pragma unroll
+        for (int i = 0; i < NSL; ++i) {
+            const int idx = i * NT + tid;
+            const int pix = (idx / (8 * CPS)) * 8 + (idx & 7);
+            spc[i] = pix < SPIX ? (pix << 8) | ((idx % (8 * CPS)) >> 3) : -1;
+        }
+    }
     float4 sty0 = make_float4(1.f, 1.f, 1.f, 1.f), sty1 = sty0;
     float osc_reg = 1.f;
     auto issue = [&](int t) {
@@ -174,6 +209,17 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) conv_thin_k(const Th
             sty0 = __builtin_bit_cast(float4, s0);
             sty1 = __builtin_bit_cast(float4, s1);
         }
+        if (DAS) {
+            const int Hs = p.Ho >> 1, Ws = p.Wo >> 1;
+            const int sy0 = ty * (TH / 2), sx0 = tx * 16;
+#pragma unroll
+            for (int i = 0; i < NSL; ++i) {
+                const int pix = spc[i] >> 8, c = spc[i] & 0xff;
+                const int sy = sy0 + (pix >> 4), sx = sx0 + (pix & 15);
+                const bool ok = spc[i] >= 0 && sy < Hs && sx < Ws;
+                sreg[i] = __builtin_amdgcn_raw_buffer_load_b128(rsc, ok ? (unsigned)((((n * Hs + sy) * Ws + sx) * SCC + c * 8) * 2) : THIN_INV, 0, 0);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             const int ly = ly0 + (hyx[i] >> 16), lx = lx0 + (hyx[i] & 0xffff);
@@ -188,6 +234,13 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) conv_thin_k(const Th
     };
     auto commit = [&]() {
         if ((G || DOT) && tid < COUT) pl[2 * COUT + tid] = p.out_scale ? osc_reg : 1.f;
+        if (DAS) {
+#pragma unroll
+            for (int i = 0; i < NSL; ++i) {
+                char* const dst = spc[i] >= 0 ? sl + (spc[i] & 0xff) * SPLANE + (spc[i] >> 8) * 16 : dump + tid * 16;
+                *reinterpret_cast<v4u*>(dst) = sreg[i];
+            }
+        }
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             const int idx = i * NT + tid;
@@ -278,6 +331,29 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) conv_thin_k(const Th
 #endif
         }
 
+        // ---- THIN_DAS: the shortcut's 1x1 transposed convolution as SCC / 32 more K steps into a second set of accumulators
+        // (the mask applies to the main path only).  Fragment pixel lpx of row r reads source pixel (r / 2, x / 2).
+        f32x4 acc2[DAS ? FCO : 1][DAS ? FPX : 1];
+        if (DAS) {
+#pragma unroll
+            for (int i = 0; i < FCO; ++i)
+#pragma unroll
+                for (int f = 0; f < FPX; ++f) acc2[i][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ss = 0; ss < SCC / 32; ++ss) {
+                bf16x8 a2[FCO];
+#pragma unroll
+                for (int i = 0; i < FCO; ++i) a2[i] = *reinterpret_cast<const bf16x8*>(swl + ((ss * 4 + kg) * COUT + i * 16 + lpx) * 16);
+#pragma unroll
+                for (int f = 0; f < FPX; ++f) {
+                    const int r = wave * RPW + (f >> 1), xl = 16 * (f & 1) + lpx;
+                    const bf16x8 b2 = *reinterpret_cast<const bf16x8*>(sl + (ss * 4 + kg) * SPLANE + ((r >> 1) * 16 + (xl >> 1)) * 16);
+#pragma unroll
+                    for (int i = 0; i < FCO; ++i) acc2[i][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[i], b2, acc2[i][f], 0, 0, 0);
+                }
+            }
+        }
+
         // ---- epilogue: lane holds channels co0..co0+3 (co0 = 16*i + 4*kg) of one pixel per slot --------
         // Unpooled: slot e = fragment e.  Pooled: the 2x2 window has its row pair in this lane (fragments
         // f, f+2) and its column pair in lane^1; even lanes store.
@@ -323,7 +399,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) conv_thin_k(const Th
                     for (int i = 0; i < FCO; ++i) {
                         const int co0 = i * 16 + kg * 4;
                         ax[k][i] = __builtin_amdgcn_raw_buffer_load_b64(raux, (live && co0 < p.Cout) ? mo[k] + co0 * 2 : THIN_INV, 0, 0);
-                        rs[k][i] = __builtin_amdgcn_raw_buffer_load_b64(rres, (live && co0 < p.Cout) ? mo[k] + co0 * 2 : THIN_INV, 0, 0);
+                        if (!DAS) rs[k][i] = __builtin_amdgcn_raw_buffer_load_b64(rres, (live && co0 < p.Cout) ? mo[k] + co0 * 2 : THIN_INV, 0, 0);
                     }
                 }
                 if (RES) {
@@ -374,9 +450,15 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) conv_thin_k(const Th
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] = lrelu_f(v[j], p.slope);
                     if (AUX) {
-                        const bf16x4 a4 = __builtin_bit_cast(bf16x4, ax[k][i]), r4 = __builtin_bit_cast(bf16x4, rs[k][i]);
+                        const bf16x4 a4 = __builtin_bit_cast(bf16x4, ax[k][i]);
+                        if (DAS) {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] = fmaf(v[j], lrelu_mask((float)a4[j], p.fu.aux_slope), (float)r4[j]);  // resid: zeros if absent
+                            for (int j = 0; j < 4; ++j) v[j] = fmaf(v[j], lrelu_mask((float)a4[j], p.fu.aux_slope), acc2[i][e][j] * p.fu.sc_gain);
+                        } else {
+                            const bf16x4 r4 = __builtin_bit_cast(bf16x4, rs[k][i]);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) v[j] = fmaf(v[j], lrelu_mask((float)a4[j], p.fu.aux_slope), (float)r4[j]);  // resid: zeros if absent
+                        }
                     }
                     if (RES) {
                         const bf16x4 r4 = __builtin_bit_cast(bf16x4, rs[k][i]);
@@ -444,7 +526,7 @@ int launch_thin_v(ThinArgs a, hipStream_t st) {
 template <int CIN, int COUT, int KS, int RPW>
 int launch_thin(const ThinArgs& a, hipStream_t st) {
     if ((a.Cout & 3) == 0) return launch_thin_v<CIN, COUT, KS, RPW, true>(a, st);
-    if constexpr (COUT == 16 && THIN_MODE != THIN_DP && THIN_MODE != THIN_DPR && THIN_MODE != THIN_DS && THIN_MODE != THIN_DPS)
+    if constexpr (COUT == 16 && THIN_MODE != THIN_DP && THIN_MODE != THIN_DPR && THIN_MODE != THIN_DS && THIN_MODE != THIN_DPS && THIN_MODE != THIN_DAS)
         return launch_thin_v<CIN, COUT, KS, RPW, false>(a, st);
     gan_set_error("conv2d_fwd(thin): Cout=%d not served", a.Cout);  // the dispatcher filters these shapes
     return GAN_ERR_ARG;
@@ -454,7 +536,12 @@ template <int CIN, int KS, int RPW>
 int pick_cout(const ThinArgs& a, hipStream_t st) {
     if (a.Cout <= 16) return launch_thin<CIN, 16, KS, RPW>(a, st);
     if (a.Cout <= 32) return launch_thin<CIN, 32, KS, RPW>(a, st);
-    return launch_thin<CIN, 64, KS, RPW>(a, st);
+    if constexpr (THIN_MODE == THIN_DAS) {  // (the dispatcher admits Cout = 16 and 32 only: the shortcut tile has 2 Cout channels)
+        gan_set_error("conv2d_fwd(thin, shortcut): Cout=%d not served", a.Cout);
+        return GAN_ERR_ARG;
+    } else {
+        return launch_thin<CIN, 64, KS, RPW>(a, st);
+    }
 }
 
 template <int KS>
@@ -477,7 +564,7 @@ int pick_cin(const ThinArgs& a, int Cin, hipStream_t st) {
             // (pooled 85.4 -> 79.3), the train step unchanged (48.85 / 48.95 ms, same box) -- the kernel's LDS reads and its
             // MFMAs each take ~31 us at 2.4 GHz and the second wave does not make them overlap.  16-row tiles on 4 waves
             // (RPW = 4): 172 us.
-            if constexpr (KS == 3) {
+            if constexpr (KS == 3 && THIN_MODE != THIN_DAS) {
                 static const bool w8 = getenv("GAN_AMD_THIN64_W8") && atoi(getenv("GAN_AMD_THIN64_W8")) == 1;
                 if (w8 && a.Cout > 32 && (a.Cout & 3) == 0) return launch_thin_v<64, 64, KS, 2, true, 8>(a, st);
             }

@@ -825,6 +825,45 @@ def raw_conv2d(
     return y if cout == cout_real else y[:, :cout_real]
 
 
+_FUSE_SHORTCUT = os.environ.get("GAN_AMD_FUSE_SC", "1") != "0"  # A/B runs: 0 = two kernels + residual read
+
+
+def raw_dblock_input_grad(g_p1: Tensor, w1: Tensor, pad: int, x_aux: Tensor, slope: float, g_s: Tensor, ws: Tensor):
+    """The input gradient of a D block's two consumers of x (progressive_gan.py:45-52) in one kernel (gan_conv2d_fwd_short):
+    m(x_aux) * dgrad3x3(g_p1, w1) + 1/4 NearestUp2(dgrad1x1(g_s, ws)) -- or None where the kernel does not serve the shape.
+    w1: (C, C, 3, 3), ws: (2C, C, 1, 1), g_p1 (N, C, H, W), g_s (N, 2C, H/2, W/2)."""
+    if not _FUSE_SHORTCUT or g_p1.dtype != torch.bfloat16 or not g_p1.is_cuda:
+        return None
+    lib = _lib.load()
+    c1o, c, kh, kw = w1.shape
+    sc_c = ws.shape[0]
+    n, cz, h, w = g_p1.shape
+    if cz != c1o or cz % 8 or tuple(ws.shape[1:]) != (c, 1, 1) or tuple(g_s.shape) != (n, sc_c, h // 2, w // 2) or tuple(x_aux.shape) != (n, c, h, w):
+        return None
+    kpad_guess = (kh * kw * cz + 31) // 32 * 32
+    if lib.gan_conv2d_fwd_short_supported(n, h, w, cz, c, kh, kw, kh - 1 - pad, kw - 1 - pad, kpad_guess, sc_c, dtype_code(g_p1)) != 1:
+        return None
+    gz = as_cl(g_p1.detach())
+    gs = as_cl(g_s.detach().to(gz.dtype))
+    wt, cz_p, kpad = pack_weight(w1, gz.dtype, cin_mult=8, transposed=True)
+    swt, sc_p, skpad = pack_weight(ws, gz.dtype, cin_mult=8, transposed=True)
+    if cz_p != cz or kpad != kpad_guess or sc_p != sc_c or skpad != sc_c:
+        return None
+    aux = as_cl(x_aux.detach().to(gz.dtype))
+    y = _empty_like_cl(gz, (n, c, h, w))
+    family = f"conv2d_fwd_thin<{cz},{16 if c <= 16 else 32},{kh},DAS>"
+    check(
+        _run(
+            family, 2.0 * n * h * w * c * (cz * kh * kw + sc_c // 4), _nbytes(gz, y, wt, aux, gs),
+            lambda: lib.gan_conv2d_fwd_short(ptr(gz), ptr(wt), ptr(y), ptr(aux), float(slope), 1.0, ptr(gs), ptr(swt), sc_c, 0.25, n, h, w, cz, c,
+                                             kh, kw, kh - 1 - pad, kw - 1 - pad, kpad, dtype_code(gz), stream_of(gz)),
+            (n, cz, h, w, c, kh, 0, 0),
+        ),
+        "gan_conv2d_fwd_short",
+    )
+    return y
+
+
 _FUSE_SCALE_DOT = os.environ.get("GAN_AMD_FUSE_SD", "1") != "0"  # A/B runs: 0 = raw_conv2d + raw_scale_dot
 
 
@@ -1296,11 +1335,15 @@ class DBlockInputFn(Function):
         pad, slope, pool_in_conv = ctx.cfg
         gx = gw1 = gb1 = gws = gbs = None
         if _need(ctx, 0):
-            if pool_in_conv:
-                gx_s = Conv2dDgradFn.apply(g_s, ws, 0, 0, None, 1.0, True)
-            else:
-                gx_s = UpFirDnFn.apply(Conv2dDgradFn.apply(g_s, ws, 0, 0), _ones_taps(x, 0.25), 2, 1, 1, 0, 1, 0)
-            gx = Conv2dDgradFn.apply(g_p1, w1, pad, pad, x, slope, False, gx_s)
+            if pool_in_conv and not torch.is_grad_enabled():
+                # thin layers, a backward pass that is not recorded: both input gradients out of one kernel
+                gx = raw_dblock_input_grad(g_p1, w1, pad, x, slope, g_s, ws)
+            if gx is None:
+                if pool_in_conv:
+                    gx_s = Conv2dDgradFn.apply(g_s, ws, 0, 0, None, 1.0, True)
+                else:
+                    gx_s = UpFirDnFn.apply(Conv2dDgradFn.apply(g_s, ws, 0, 0), _ones_taps(x, 0.25), 2, 1, 1, 0, 1, 0)
+                gx = Conv2dDgradFn.apply(g_p1, w1, pad, pad, x, slope, False, gx_s)
         if _need(ctx, 1) and b1 is not None and _need(ctx, 2):
             gw1, gb1 = _wgrad_and_bias_for(w1, b1, x, g_p1, pad, pad, slope, False)
         else:

@@ -365,6 +365,20 @@ int gan_conv2d_fwd_dot(const void* x, const void* wt, void* y, const float* out_
                        int Cin, int Ho, int Wo, int Cout, int kh, int kw, int py, int px, int Kpad, int pool, float gain, int dtype,
                        gan_stream_t stream);
 
+/* ---- input gradient of a D block's two consumers of x in one kernel ----------------------------
+ * replaces the backward of `self.layers[1](self.layers[0](x))` and `self.shortcut(x)` w.r.t. x    modelling/progressive_gan.py:45-52
+ *   y = LeakyReLU'(aux) * (conv(x, wt) * gain) + sc_gain * NearestUp2( conv1x1(sc_x, sc_w) )
+ * x = the gradient at conv1's output (N, H, W, Cin), wt = conv1's packed transposed / flipped weights, aux = the block input
+ * (its sign decides the mask), sc_x = the gradient at the shortcut's output (N, H/2, W/2, sc_c = 2 Cout), sc_w = the shortcut's
+ * packed transposed 1x1 weights [Cout][sc_c], sc_gain = 1/4 (the adjoint of AvgPool2d(2)).  The shortcut term is sc_c / 32 more
+ * K steps of the same tile into a second set of accumulators -- without this entry it is a kernel of its own that writes a
+ * full-resolution tensor which gan_conv2d_fwd(..., resid) reads back.  Thin layers with Cout 16 or 32:
+ * gan_conv2d_fwd_short_supported(...) == 1. */
+int gan_conv2d_fwd_short_supported(int N, int H, int W, int Cin, int Cout, int kh, int kw, int py, int px, int Kpad, int sc_c, int dtype);
+int gan_conv2d_fwd_short(const void* x, const void* wt, void* y, const void* aux, float aux_slope, float gain, const void* sc_x,
+                         const void* sc_w, int sc_c, float sc_gain, int N, int H, int W, int Cin, int Cout, int kh, int kw, int py, int px,
+                         int Kpad, int dtype, gan_stream_t stream);
+
 /* ---- convolution parameters scaled per output channel ------------------------------------
  * replaces the activation-sized multiply of `self.shortcut(x) + self.layers(x) * self.scale`   modelling/progressive_gan.py:54
  * conv(x, W) * scale + b * scale = conv(x, W * scale) + b * scale: the block's last convolution runs on

@@ -1531,3 +1531,32 @@ def test_conv2d_dgrad_scale_dot(dev, case):
     with GF.zeroed_scratch(dev):
         gx3, gs3 = GF.raw_conv2d_dgrad_scale_dot(gz, weight, tpad, tpad, s, xin, pool=pooled, gain=4.0 if pooled else 1.0)
         assert torch.equal(gx3, gx) and rel_err(gs3, want_gs) < 2e-3
+
+
+@pytest.mark.parametrize("case", [(3, 16, 64, 64), (2, 32, 40, 64), (5, 16, 48, 96), (2, 32, 64, 64), (33, 16, 32, 32)])
+def test_dblock_input_grad_fused(dev, case):
+    """gan_conv2d_fwd_short: the input gradient of a D block's two consumers of x (progressive_gan.py:45-52) in one kernel --
+    LeakyReLU'(x) * dgrad3x3(g_p1, W1) + 1/4 NearestUp2(dgrad1x1(g_s, Ws)) -- against fp64 and against the two-kernel path
+    (shortcut gradient written out, read back as the residual); ragged tiles, more tiles than workgroups."""
+    import torch.nn.functional as F
+
+    import gan_amd.functional as GF
+
+    n, c, h, w = case
+    torch.manual_seed(sum(case))
+    g_p1 = torch.randn(n, c, h, w, device=dev).bfloat16().contiguous(memory_format=torch.channels_last)
+    g_s = torch.randn(n, 2 * c, h // 2, w // 2, device=dev).bfloat16().contiguous(memory_format=torch.channels_last)
+    x = torch.randn(n, c, h, w, device=dev).bfloat16().contiguous(memory_format=torch.channels_last)
+    w1 = torch.randn(c, c, 3, 3, device=dev) / (9 * c) ** 0.5
+    ws = torch.randn(2 * c, c, 1, 1, device=dev) / c ** 0.5
+    got = GF.raw_dblock_input_grad(g_p1, w1, 1, x, 0.2, g_s, ws)
+    assert got is not None, "shape not served by the fused kernel"
+    mask = torch.where(x.double() > 0, 1.0, 0.2)
+    main = F.conv_transpose2d(g_p1.double(), w1.bfloat16().double(), padding=1) * mask
+    short = F.interpolate(F.conv_transpose2d(g_s.double(), ws.bfloat16().double()), scale_factor=2, mode="nearest") * 0.25
+    want = main + short
+    assert got.shape == want.shape and got.dtype == torch.bfloat16
+    assert rel_err(got, want) < 6e-3, rel_err(got, want)
+    gx_s = GF.raw_conv2d_dgrad(g_s, ws, 0, 0, pooled=True)
+    two = GF.raw_conv2d_dgrad(g_p1, w1, 1, 1, aux=x, aux_slope=0.2, resid=gx_s)
+    assert rel_err(got, two) < 1e-2
