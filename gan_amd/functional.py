@@ -1307,6 +1307,34 @@ class Conv2dDgradFn(Function):
         return g_gy, g_w, None, None, None, None, None, g_resid
 
 
+class DBlockInputGradFn(Function):
+    """gx = m(x) * dgrad3x3(g_p1, W1) + 1/4 NearestUp2(dgrad1x1(g_s, Ws)): the input gradient of a thin D block's two consumers
+    of x (DBlockInputFn below) as ONE kernel (gan_conv2d_fwd_short) -- the shortcut's gradient is never written out.  Bilinear in
+    (g_p1, W1) and (g_s, Ws) for a fixed mask; its backward is the pair of Conv2dDgradFn backwards it replaces, so R1's second
+    order runs through it too."""
+
+    @staticmethod
+    def forward(ctx, g_p1, g_s, w1, ws, x, pad, slope):
+        ctx.save_for_backward(g_p1, g_s, w1, ws, x)
+        ctx.cfg = (pad, slope)
+        y = raw_dblock_input_grad(g_p1, w1, pad, x, slope, g_s, ws)
+        if y is None:  # (fp32, odd shapes: the two kernels, the shortcut's gradient as the residual of the other)
+            gx_s = raw_conv2d_dgrad(g_s, ws, 0, 0, pooled=True)
+            y = raw_conv2d_dgrad(g_p1, w1, pad, pad, aux=x, aux_slope=slope, resid=gx_s)
+        return y
+
+    @staticmethod
+    def backward(ctx, ggx):
+        g_p1, g_s, w1, ws, x = ctx.saved_tensors
+        pad, slope = ctx.cfg
+        z = MaskMulFn.apply(ggx, x, slope)
+        g_gp1 = Conv2dFn.apply(z, w1, pad, pad, 1.0, False).to(g_p1.dtype) if _need(ctx, 0) else None
+        g_gs = Conv2dFn.apply(ggx, ws, 0, 0, 1.0, True).to(g_s.dtype) if _need(ctx, 1) else None
+        g_w1 = _wgrad_for(w1, z, g_p1, pad, pad, 1.0, False) if _need(ctx, 2) else None
+        g_ws = _wgrad_for(ws, ggx, g_s, 0, 0, 1.0, True) if _need(ctx, 3) else None
+        return g_gp1, g_gs, g_w1, g_ws, None, None, None
+
+
 class DBlockInputFn(Function):
     """The two consumers of a discriminator block's input x (progressive_gan.py:45-46,52):
          p1 = conv3x3(leaky_relu(x), W1) + b1          s = AvgPool2d(2) -> conv1x1(Ws)
@@ -1335,14 +1363,10 @@ class DBlockInputFn(Function):
         pad, slope, pool_in_conv = ctx.cfg
         gx = gw1 = gb1 = gws = gbs = None
         if _need(ctx, 0):
-            if pool_in_conv and not torch.is_grad_enabled():
-                # thin layers, a backward pass that is not recorded: both input gradients out of one kernel
-                gx = raw_dblock_input_grad(g_p1, w1, pad, x, slope, g_s, ws)
-            if gx is None:
-                if pool_in_conv:
-                    gx_s = Conv2dDgradFn.apply(g_s, ws, 0, 0, None, 1.0, True)
-                else:
-                    gx_s = UpFirDnFn.apply(Conv2dDgradFn.apply(g_s, ws, 0, 0), _ones_taps(x, 0.25), 2, 1, 1, 0, 1, 0)
+            if pool_in_conv:  # thin layers: both input gradients out of one kernel
+                gx = DBlockInputGradFn.apply(g_p1, g_s, w1, ws, x, pad, slope)
+            else:
+                gx_s = UpFirDnFn.apply(Conv2dDgradFn.apply(g_s, ws, 0, 0), _ones_taps(x, 0.25), 2, 1, 1, 0, 1, 0)
                 gx = Conv2dDgradFn.apply(g_p1, w1, pad, pad, x, slope, False, gx_s)
         if _need(ctx, 1) and b1 is not None and _need(ctx, 2):
             gw1, gb1 = _wgrad_and_bias_for(w1, b1, x, g_p1, pad, pad, slope, False)
