@@ -521,7 +521,7 @@ extern "C" int gan_conv2d_fwd_short_supported(int N, int H, int W, int Cin, int 
     if (dtype != GAN_BF16 || N <= 0) return 0;
     if (kh != 3 || kw != 3 || py != 1 || px != 1) return 0;
     if (Cin != 8 && Cin != 16 && Cin != 32 && Cin != 64) return 0;
-    if ((Cout != 16 && Cout != 32) || sc_c != 2 * Cout || W < 32 || H < 8 || (H & 1) || (W & 1)) return 0;
+    if ((Cout != 16 && Cout != 32 && !(Cout == 64 && Cin == 64)) || sc_c != 2 * Cout || W < 32 || H < 8 || (H & 1) || (W & 1)) return 0;
     if (Kpad != (9 * Cin + 31) / 32 * 32) return 0;
     const int64_t big = (int64_t)N * H * W * (Cin > Cout ? Cin : Cout) * 2;
     if (big >= (1LL << 31) || (int64_t)N * H * W >= (1LL << 31)) return 0;
@@ -533,7 +533,7 @@ extern "C" int gan_conv2d_fwd_short(const void* x, const void* wt, void* y, cons
                                     int px, int Kpad, int dtype, gan_stream_t stream) {
     GAN_CHECK_ARG(aux && sc_x && sc_w, "conv2d_fwd_short: null pointer");
     GAN_CHECK_ARG(gan_conv2d_fwd_short_supported(N, H, W, Cin, Cout, kh, kw, py, px, Kpad, sc_c, dtype) == 1,
-                  "conv2d_fwd_short: shape not served (bf16, 3 x 3, Cout 16 or 32, sc_c = 2 Cout, even maps >= 32 pixels wide)");
+                  "conv2d_fwd_short: shape not served (bf16, 3 x 3, Cout 16 or 32 -- 64 with Cin 64 --, sc_c = 2 Cout, even maps >= 32 pixels wide)");
     GAN_CHECK_ARG(((uintptr_t)y % 8) == 0 && ((uintptr_t)aux % 8) == 0 && ((uintptr_t)sc_x % 16) == 0 && ((uintptr_t)sc_w % 16) == 0,
                   "conv2d_fwd_short: y / aux must be 8-byte, sc_x / sc_w 16-byte aligned");
     return conv2d_fwd_impl(x, wt, y, nullptr, nullptr, nullptr, nullptr, nullptr, 1.f, N, H, W, Cin, 0, H, W, Cout, kh, kw, py, px, Kpad, 1.f, 0, aux,

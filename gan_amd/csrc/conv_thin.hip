@@ -20,7 +20,7 @@ int gan_conv2d_fwd_thin(const void* x, const void* wt, void* y, const float* in_
     if (fu.sc_x) {
         // the D block's conv1 input gradient with the shortcut's input gradient formed in the kernel (THIN_DAS)
         if (fu.dot_out || !fu.aux || fu.resid || fu.pool || in_scale || out_scale || noise || bias || up2 || fu.in_slope != 1.f || slope != 1.f) return 0;
-        if (kh != 3 || (Cout != 16 && Cout != 32) || fu.sc_c != 2 * Cout || !fu.sc_w || (Ho & 1) || (Wo & 1)) return 0;
+        if (kh != 3 || (Cout != 16 && Cout != 32 && !(Cout == 64 && Cin == 64)) || fu.sc_c != 2 * Cout || !fu.sc_w || (Ho & 1) || (Wo & 1)) return 0;
         if (((uintptr_t)fu.sc_x % 16) != 0 || ((uintptr_t)fu.sc_w % 16) != 0) return 0;
         if ((int64_t)N * (Ho / 2) * (Wo / 2) * fu.sc_c * 2 >= (1LL << 31)) return 0;
     }

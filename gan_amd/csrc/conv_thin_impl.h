@@ -536,7 +536,8 @@ template <int CIN, int KS, int RPW>
 int pick_cout(const ThinArgs& a, hipStream_t st) {
     if (a.Cout <= 16) return launch_thin<CIN, 16, KS, RPW>(a, st);
     if (a.Cout <= 32) return launch_thin<CIN, 32, KS, RPW>(a, st);
-    if constexpr (THIN_MODE == THIN_DAS) {  // (the dispatcher admits Cout = 16 and 32 only: the shortcut tile has 2 Cout channels)
+    if constexpr (THIN_MODE == THIN_DAS && (CIN != 64 || KS != 3)) {
+        // (64 output channels: the shortcut tile has 128 channels -- 32 KB more LDS, instantiated for the one layer that has it)
         gan_set_error("conv2d_fwd(thin, shortcut): Cout=%d not served", a.Cout);
         return GAN_ERR_ARG;
     } else {

@@ -851,7 +851,7 @@ def raw_dblock_input_grad(g_p1: Tensor, w1: Tensor, pad: int, x_aux: Tensor, slo
         return None
     aux = as_cl(x_aux.detach().to(gz.dtype))
     y = _empty_like_cl(gz, (n, c, h, w))
-    family = f"conv2d_fwd_thin<{cz},{16 if c <= 16 else 32},{kh},DAS>"
+    family = f"conv2d_fwd_thin<{cz},{16 if c <= 16 else (32 if c <= 32 else 64)},{kh},DAS>"
     check(
         _run(
             family, 2.0 * n * h * w * c * (cz * kh * kw + sc_c // 4), _nbytes(gz, y, wt, aux, gs),
@@ -1363,7 +1363,8 @@ class DBlockInputFn(Function):
         pad, slope, pool_in_conv = ctx.cfg
         gx = gw1 = gb1 = gws = gbs = None
         if _need(ctx, 0):
-            if pool_in_conv:  # thin layers: both input gradients out of one kernel
+            if pool_in_conv or (w1.shape[0] == 64 and w1.shape[1] == 64 and x.dtype == torch.bfloat16 and x.shape[3] >= 32):
+                # thin conv1 (64 -> 64 too, whose shortcut ran on the wide kernels forward): both input gradients out of one kernel
                 gx = DBlockInputGradFn.apply(g_p1, g_s, w1, ws, x, pad, slope)
             else:
                 gx_s = UpFirDnFn.apply(Conv2dDgradFn.apply(g_s, ws, 0, 0), _ones_taps(x, 0.25), 2, 1, 1, 0, 1, 0)

@@ -372,7 +372,7 @@ int gan_conv2d_fwd_dot(const void* x, const void* wt, void* y, const float* out_
  * (its sign decides the mask), sc_x = the gradient at the shortcut's output (N, H/2, W/2, sc_c = 2 Cout), sc_w = the shortcut's
  * packed transposed 1x1 weights [Cout][sc_c], sc_gain = 1/4 (the adjoint of AvgPool2d(2)).  The shortcut term is sc_c / 32 more
  * K steps of the same tile into a second set of accumulators -- without this entry it is a kernel of its own that writes a
- * full-resolution tensor which gan_conv2d_fwd(..., resid) reads back.  Thin layers with Cout 16 or 32:
+ * full-resolution tensor which gan_conv2d_fwd(..., resid) reads back.  Thin layers with Cout 16 or 32 (64 with Cin 64):
  * gan_conv2d_fwd_short_supported(...) == 1. */
 int gan_conv2d_fwd_short_supported(int N, int H, int W, int Cin, int Cout, int kh, int kw, int py, int px, int Kpad, int sc_c, int dtype);
 int gan_conv2d_fwd_short(const void* x, const void* wt, void* y, const void* aux, float aux_slope, float gain, const void* sc_x,

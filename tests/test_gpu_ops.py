@@ -1533,7 +1533,7 @@ def test_conv2d_dgrad_scale_dot(dev, case):
         assert torch.equal(gx3, gx) and rel_err(gs3, want_gs) < 2e-3
 
 
-@pytest.mark.parametrize("case", [(3, 16, 64, 64), (2, 32, 40, 64), (5, 16, 48, 96), (2, 32, 64, 64), (33, 16, 32, 32)])
+@pytest.mark.parametrize("case", [(3, 16, 64, 64), (2, 32, 40, 64), (5, 16, 48, 96), (2, 32, 64, 64), (33, 16, 32, 32), (3, 64, 32, 64), (9, 64, 64, 64)])
 def test_dblock_input_grad_fused(dev, case):
     """gan_conv2d_fwd_short: the input gradient of a D block's two consumers of x (progressive_gan.py:45-52) in one kernel --
     LeakyReLU'(x) * dgrad3x3(g_p1, W1) + 1/4 NearestUp2(dgrad1x1(g_s, Ws)) -- against fp64 and against the two-kernel path
