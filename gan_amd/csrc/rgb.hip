@@ -61,18 +61,34 @@ __global__ void __launch_bounds__(RTPB) rgb_fwd_k(const TI* __restrict__ x, int6
         br[j] = bl[c8 + j];
     }
     const unsigned n = blockIdx.y;
+    // fp32 images: the values of all RGB_FWD_PX pixels first (their loads in flight together: 154 -> 140 us at 256 x 3 x 256^2),
+    // then the products and the stores.  2-byte channels-last pixels are loaded pixel by pixel (batched: 192 -> 230 us).
+    constexpr bool BATCH = sizeof(TI) == 4;
+    float xv[RGB_FWD_PX][RGB_MAXC];
+    unsigned pp[RGB_FWD_PX];
 #pragma unroll
     for (unsigned it = 0; it < RGB_FWD_PX; ++it) {
         const unsigned p = (blockIdx.x * RGB_FWD_PX + it) * PPB + lp;
-        if (p >= HW) break;
-        const TI* __restrict__ xp = x + rgb_xoff(n, p, sn, sh, sw, W, lin);
-        float xv[RGB_MAXC];
+        pp[it] = p;
+        if (BATCH) {
+            const TI* __restrict__ xp = x + rgb_xoff(n, p < HW ? p : 0u, sn, sh, sw, W, lin);
 #pragma unroll
-        for (int c = 0; c < RGB_MAXC; ++c) xv[c] = c < Cin ? ldf(xp + c * sc) : 0.f;
+            for (int c = 0; c < RGB_MAXC; ++c) xv[it][c] = c < Cin ? ldf(xp + c * sc) : 0.f;
+        }
+    }
+#pragma unroll
+    for (unsigned it = 0; it < RGB_FWD_PX; ++it) {
+        const unsigned p = pp[it];
+        if (p >= HW) break;
+        if (!BATCH) {
+            const TI* __restrict__ xp = x + rgb_xoff(n, p, sn, sh, sw, W, lin);
+#pragma unroll
+            for (int c = 0; c < RGB_MAXC; ++c) xv[it][c] = c < Cin ? ldf(xp + c * sc) : 0.f;
+        }
         float o[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-            o[j] = lrelu_f(fmaf(xv[0], wr[j].x, fmaf(xv[1], wr[j].y, fmaf(xv[2], wr[j].z, fmaf(xv[3], wr[j].w, br[j])))), slope);
+            o[j] = lrelu_f(fmaf(xv[it][0], wr[j].x, fmaf(xv[it][1], wr[j].y, fmaf(xv[it][2], wr[j].z, fmaf(xv[it][3], wr[j].w, br[j])))), slope);
         TO* __restrict__ yp = y + ((int64_t)n * HW + p) * COUT + c8;
         if constexpr (sizeof(TO) == 2) {
             store_f<TO, 8>(yp, o);
