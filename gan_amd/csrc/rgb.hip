@@ -35,11 +35,14 @@ __device__ __forceinline__ int64_t rgb_xoff(unsigned n, unsigned p, int64_t sn, 
 // fwd: one thread = one pixel x 8 output channels; CV = Cout / 8 consecutive lanes share a pixel, so a wave's 16-byte
 // stores are one contiguous run.  grid.y = sample.  Weights sit in LDS padded to 4 input channels (one ds_read_b128
 // per output channel, the same address for every lane: a broadcast).
-template <typename TI, typename TO, int CV>
+// DENSE: a dense channels-last 2-byte image (the generator's output): a workgroup's pixels are one contiguous byte run, read
+// with 16-byte loads into LDS (a pixel is 6 bytes: per-lane 2-byte loads at a 6-byte stride ran at 3.3 TB/s of in + out bytes)
+template <typename TI, typename TO, int CV, bool DENSE = false>
 __global__ void __launch_bounds__(RTPB) rgb_fwd_k(const TI* __restrict__ x, int64_t sn, int64_t sc, int64_t sh, int64_t sw, unsigned W, int lin,
                                                   const float* __restrict__ wgt, const float* __restrict__ bias, TO* __restrict__ y, unsigned HW,
                                                   int Cin, float slope) {
     constexpr int COUT = CV * 8;
+    __shared__ __attribute__((aligned(16))) TI xl[DENSE ? RGB_FWD_PX * (RTPB / CV) * RGB_MAXC + 8 : 8];
     __shared__ float4 wl[COUT];
     __shared__ float bl[COUT];
     for (int i = threadIdx.x; i < COUT; i += RTPB) {
@@ -61,6 +64,21 @@ __global__ void __launch_bounds__(RTPB) rgb_fwd_k(const TI* __restrict__ x, int6
         br[j] = bl[c8 + j];
     }
     const unsigned n = blockIdx.y;
+    if (DENSE) {  // this workgroup's pixels: elements [p0 * Cin, p1 * Cin) of image n, 16-byte aligned (host-checked)
+        constexpr int EPV = 16 / sizeof(TI);
+        const unsigned p0 = blockIdx.x * RGB_FWD_PX * PPB;
+        const unsigned p1 = p0 + RGB_FWD_PX * PPB < HW ? p0 + RGB_FWD_PX * PPB : HW;
+        const int nel = p1 > p0 ? (int)(p1 - p0) * Cin : 0;
+        const TI* __restrict__ src = x + ((int64_t)n * HW + p0) * Cin;
+        for (int i = threadIdx.x * EPV; i < nel; i += RTPB * EPV) {
+            if (i + EPV <= nel) {
+                *reinterpret_cast<uint4*>(xl + i) = *reinterpret_cast<const uint4*>(src + i);
+            } else {
+                for (int e = i; e < nel; ++e) xl[e] = src[e];
+            }
+        }
+        __syncthreads();
+    }
     // fp32 images: the values of all RGB_FWD_PX pixels first (their loads in flight together: 154 -> 140 us at 256 x 3 x 256^2),
     // then the products and the stores.  2-byte channels-last pixels are loaded pixel by pixel (batched: 192 -> 230 us).
     constexpr bool BATCH = sizeof(TI) == 4;
@@ -70,7 +88,7 @@ __global__ void __launch_bounds__(RTPB) rgb_fwd_k(const TI* __restrict__ x, int6
     for (unsigned it = 0; it < RGB_FWD_PX; ++it) {
         const unsigned p = (blockIdx.x * RGB_FWD_PX + it) * PPB + lp;
         pp[it] = p;
-        if (BATCH) {
+        if (BATCH && !DENSE) {
             const TI* __restrict__ xp = x + rgb_xoff(n, p < HW ? p : 0u, sn, sh, sw, W, lin);
 #pragma unroll
             for (int c = 0; c < RGB_MAXC; ++c) xv[it][c] = c < Cin ? ldf(xp + c * sc) : 0.f;
@@ -80,7 +98,10 @@ __global__ void __launch_bounds__(RTPB) rgb_fwd_k(const TI* __restrict__ x, int6
     for (unsigned it = 0; it < RGB_FWD_PX; ++it) {
         const unsigned p = pp[it];
         if (p >= HW) break;
-        if (!BATCH) {
+        if (DENSE) {
+#pragma unroll
+            for (int c = 0; c < RGB_MAXC; ++c) xv[it][c] = c < Cin ? (float)xl[(it * PPB + lp) * Cin + c] : 0.f;
+        } else if (!BATCH) {
             const TI* __restrict__ xp = x + rgb_xoff(n, p, sn, sh, sw, W, lin);
 #pragma unroll
             for (int c = 0; c < RGB_MAXC; ++c) xv[it][c] = c < Cin ? ldf(xp + c * sc) : 0.f;
@@ -334,8 +355,18 @@ extern "C" int gan_rgb_conv1x1_fwd(const void* x, int x_dtype, int64_t sn, int64
     const dim3 grid((unsigned)ceil_div64(HW * CV, (int64_t)RTPB * RGB_FWD_PX), (unsigned)N);
     const int lin = sh == (int64_t)W * sw;
     hipStream_t st = (hipStream_t)stream;
-#define RGB_FWD3(TI, TO, CV_) \
-    hipLaunchKernelGGL((rgb_fwd_k<TI, TO, CV_>), grid, dim3(RTPB), 0, st, (const TI*)x, sn, sc, sh, sw, (unsigned)W, lin, w, bias, (TO*)y, (unsigned)HW, Cin, slope)
+    // a dense channels-last 2-byte image whose per-workgroup runs start on 16-byte boundaries
+    const bool dense = x_dtype == GAN_BF16 && sc == 1 && sw == Cin && sh == (int64_t)W * Cin && sn == HW * Cin && ((uintptr_t)x % 16) == 0 &&
+                       (HW * Cin * 2) % 16 == 0 && ((int64_t)RGB_FWD_PX * (RTPB / CV) * Cin * 2) % 16 == 0;
+#define RGB_FWD3(TI, TO, CV_)                                                                                                                      \
+    do {                                                                                                                                           \
+        if (dense && sizeof(TI) == 2)                                                                                                              \
+            hipLaunchKernelGGL((rgb_fwd_k<TI, TO, CV_, sizeof(TI) == 2>), grid, dim3(RTPB), 0, st, (const TI*)x, sn, sc, sh, sw, (unsigned)W, lin, w, \
+                               bias, (TO*)y, (unsigned)HW, Cin, slope);                                                                            \
+        else                                                                                                                                       \
+            hipLaunchKernelGGL((rgb_fwd_k<TI, TO, CV_>), grid, dim3(RTPB), 0, st, (const TI*)x, sn, sc, sh, sw, (unsigned)W, lin, w, bias, (TO*)y,  \
+                               (unsigned)HW, Cin, slope);                                                                                          \
+    } while (0)
 #define RGB_FWD(TI, TO)                     \
     do {                                    \
         if (CV == 1) RGB_FWD3(TI, TO, 1);   \
