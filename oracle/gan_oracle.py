@@ -109,6 +109,27 @@ def blur_conv_down(sd: Mapping[str, Tensor], x: Tensor, kernel_size: int, blur_s
 # --------------------------------------------------------------------------------------
 # modelling/stylegan2.py + modelling/stylegan.py:Noise
 # --------------------------------------------------------------------------------------
+# Test hook (tests/test_gpu_config4.py): emulate an implementation that STORES activations, their gradients and the
+# convolution weights in a narrower dtype while computing in this oracle's own: with STORE_DTYPE set, those tensors are
+# rounded to it (straight through: the gradient passes, itself rounded).  None (the default): the reference's arithmetic.
+STORE_DTYPE = None
+
+
+class _StoreRound(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, dtype):
+        ctx.dtype = dtype
+        return x.to(dtype).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(ctx.dtype).to(g.dtype), None
+
+
+def _stored(x: Tensor) -> Tensor:
+    return x if STORE_DTYPE is None else _StoreRound.apply(x, STORE_DTYPE)
+
+
 def modulated_conv2d(
     x: Tensor, w: Tensor, weight: Tensor, bias: Tensor, style_weight: Tensor, style_bias: Tensor, demodulation: bool
 ) -> Tensor:
@@ -117,6 +138,7 @@ def modulated_conv2d(
     n, cin, h, wd = x.shape
     cout, _, kh, kw = weight.shape
     style = F.linear(w, style_weight, style_bias) + 1  # (N, Cin)
+    weight = _stored(weight)
     wmod = weight.unsqueeze(0) * style.view(n, 1, cin, 1, 1)  # (N, Cout, Cin, kh, kw)
     if demodulation:
         norm = wmod.square().sum(dim=(2, 3, 4), keepdim=True).sqrt()
@@ -195,8 +217,8 @@ def generator_block(
         if blur_size is not None and not first and j == 0:
             x = blur(x, blur_size)
         x = add_noise(x, sd[f"{prefix}layers.{ni}.scale"], feed.next())
-        x = bias_leaky_relu(x, None)
-    rgb = _modconv_from(sd, f"{prefix}to_rgb.", x, w, False)
+        x = _stored(bias_leaky_relu(x, None))
+    rgb = _stored(_modconv_from(sd, f"{prefix}to_rgb.", x, w, False))
     return x, rgb
 
 
@@ -205,11 +227,11 @@ def generator(sd: Mapping[str, Tensor], z: Tensor, noises: Optional[Sequence[Ten
     feed = _NoiseFeed(noises)
     w = mapping_network(sd, z)
     n_blocks = 1 + max(int(k.split(".")[1]) for k in sd if k.startswith("blocks."))
-    x = sd["learned_input"].expand(z.shape[0], -1, -1, -1)
+    x = _stored(sd["learned_input"].expand(z.shape[0], -1, -1, -1))
     x, y = generator_block(sd, "blocks.0.", x, w, True, feed)
     for b in range(1, n_blocks):
         x, rgb = generator_block(sd, f"blocks.{b}.", x, w, False, feed, blur_size)
-        y = nearest_up2(y) + rgb
+        y = _stored(nearest_up2(y) + rgb)
     return y
 
 

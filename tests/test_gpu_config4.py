@@ -201,10 +201,12 @@ def test_generator256_vs_oracle(dev, mixed):
     parameter gradient against the oracle in fp64 (literal per-sample-weight grouped convolution).
     fp32: 1e-5, or 4x what the SAME oracle run in fp32 on the CPU achieves against its fp64 run on that tensor
     (weight gradients at 256x256 are 262 144-term sums).
-    bf16: 1e-2 on the image and on the gradient as one vector (north_star's figure); 3e-2 per tensor, except the
-    Noise.scale gradients (sum over pixels of g * noise, a random-sign sum that is itself only ~sqrt(N) of its terms:
-    bf16's incoherent 1e-2 per-element error does not average out of it): 1.5e-1.  The reference keeps
-    ModulatedConv2d in fp32 under autocast, so it offers no bf16 yardstick for the generator."""
+    bf16: 1e-2 on the image and on the gradient as one vector (north_star's figure).  Per tensor the bound is DERIVED: the
+    reference keeps ModulatedConv2d in fp32 under autocast and so offers no bf16 run of the generator, but the
+    fp64 oracle can be told to STORE activations, their gradients and the convolution weights in bf16 while computing in fp64
+    (oracle.gan_oracle.STORE_DTYPE) -- the rounding any bf16-storage implementation has, with none of its arithmetic error.
+    A tensor passes at 3e-2 or at 3x what that run is off by on the same tensor (the Noise.scale gradients -- sums over pixels
+    of g * noise with random signs, only ~sqrt(N) of their terms -- are where it matters)."""
     from gan_amd.modelling import build_generator
     from oracle import gan_oracle as O
     from oracle.detparams import det_uniform
@@ -224,10 +226,14 @@ def test_generator256_vs_oracle(dev, mixed):
     loss.backward()
     got = {k: p.grad for k, p in gen.named_parameters()}
 
-    def oracle(dtype):
+    def oracle(dtype, store=None):
         sd = {k: v.detach().clone().to(dtype).requires_grad_(True) for k, v in state.items()}
-        img_o = O.generator(sd, z.to(dtype), [t.to(dtype) for t in rec.tape])
-        ((img_o * wgt.to(dtype)).sum() / 1000.0 + img_o.square().mean()).backward()
+        O.STORE_DTYPE = store
+        try:
+            img_o = O.generator(sd, z.to(dtype), [t.to(dtype) for t in rec.tape])
+            ((img_o * wgt.to(dtype)).sum() / 1000.0 + img_o.square().mean()).backward()
+        finally:
+            O.STORE_DTYPE = None
         return img_o.detach(), {k: v.grad.double() for k, v in sd.items()}
 
     img_o, ref = oracle(torch.float64)
@@ -243,12 +249,15 @@ def test_generator256_vs_oracle(dev, mixed):
         for k, e in errs.items():
             assert e < max(TOL, 4.0 * floor[k]), (k, e, floor[k])
     else:
-        print(msg)
+        _, stored = oracle(torch.float64, store=torch.bfloat16)
+        yard, total_yard = _tensor_errs(stored, ref)
+        wk = max(yard.items(), key=lambda kv: kv[1])
+        print(msg + f"; fp64 oracle with bf16 storage: all grads {total_yard:.2e}, worst tensor {wk[0]} {wk[1]:.2e}")
         assert img.dtype == torch.bfloat16
         assert rel_err(img, img_o) < TOLBF
         assert total < TOLBF, total
         for k, e in errs.items():
-            assert e < (1.5e-1 if k.endswith(".scale") else 3e-2), (k, e)
+            assert e < max(3e-2, 3.0 * yard[k]), (k, e, yard[k])
 
 
 # ------------------------------------------------------------------------------------------------------
