@@ -293,15 +293,19 @@ def test_trajectory16_golden(dev, golden):
     """10 free-running hinge + R1 iterations (Adam 2e-4, betas (0, 0.9)) against the losses the reference
     itself produced, with the reference's recorded random draws.  The iteration is chaotic (see
     oracle/make_envelope.py: the oracle in fp32 and in fp64 drifts apart by O(1) within 10 steps), so
-    each step is held to 1e-4 relative OR 10x the recorded fp32-vs-fp64 envelope of that step (25x from
-    step 5 on: the fp32 atomics of the small-shape reductions make the GPU run itself vary from launch
-    to launch, and the iteration amplifies that too)."""
+    each step is held to 1e-4 relative OR 10x the recorded fp32-vs-fp64 envelope of that step, measured
+    from the nearer of the two recorded trajectories (observed: <= 3.3x; the fp32 atomics of the
+    small-shape reductions make the GPU run itself vary from launch to launch, and the iteration
+    amplifies that too).  Inside the predictability horizon the bounds are strict: steps 0-2 against
+    the reference's fp32 losses, steps 0-3 against the fp64 oracle's, which the HIP path follows for
+    longer than the reference's own fp32 run does (step 3: 2e-5 against 1.4e-3)."""
     from oracle import gan_oracle as O
     from oracle.detparams import det_state, det_uniform, projections
     from oracle.tape import RandTape
 
     g = golden("trajectory16")
     env = golden("trajectory16_envelope")["envelope"]
+    traj64 = golden("trajectory16_envelope")["fp64"]
     g_state = det_state(O.stylegan2_generator_shapes(16, base_dim=128), seed=g["gen_seed"], bias_amp=0.0, scale_amp=0.05)
     d_state = det_state(O.stylegan2_discriminator_shapes(16, base_dim=16), seed=g["disc_seed"], bias_amp=0.0, scale_amp=0.5)
     tr = _trainer16(dev, g_state, d_state, warmup=g["ema_warmup"])
@@ -312,8 +316,12 @@ def test_trajectory16_golden(dev, golden):
         ref = g["steps"][step]
         for j, key in enumerate(("loss/d", "loss/g")):
             got, want = float(logs[key]), float(ref[j])
-            tol = max(1e-4 * max(1.0, abs(want)), (10.0 if step < 5 else 25.0) * float(env[step, j]))
-            assert abs(got - want) <= tol, (step, key, got, want, tol)
+            f64 = float(traj64[step, j])
+            tol = max(1e-4 * max(1.0, abs(want)), 10.0 * float(env[step, j]))
+            print(f"trajectory16 step {step} {key}: |got - reference fp32| {abs(got - want):.2e}, |got - oracle fp64| {abs(got - f64):.2e}, envelope {float(env[step, j]):.2e}")
+            assert min(abs(got - want), abs(got - f64)) <= tol, (step, key, got, want, f64, tol)
+            if step <= 3:
+                assert math.isclose(got, f64, rel_tol=2e-4, abs_tol=2e-4), (step, key, got, f64)
         if step < 3:  # inside the predictability horizon: strict
             assert math.isclose(float(logs["loss/d"]), float(ref[0]), rel_tol=1e-4, abs_tol=1e-5), (step, logs, ref)
             assert math.isclose(float(logs["loss/g"]), float(ref[1]), rel_tol=1e-4, abs_tol=1e-5), (step, logs, ref)
