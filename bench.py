@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--base_dim", type=int, default=16)
     ap.add_argument("--recipe", choices=["stylegan2", "dcgan"], default="stylegan2",
                     help="stylegan2: hinge+R1 (BASELINE configs 3/4); dcgan: DCGAN WGAN-GP n_disc=5 at 64x64 (config 5, README.md:55)")
+    ap.add_argument("--blur_size", type=int, default=None,
+                    help="FIR low-pass of this size in the StyleGAN2 blocks (not a BASELINE config: the reference leaves them out)")
     ap.add_argument("--fp32", action="store_true", help="fp32 instead of bf16 autocast (debug)")
     ap.add_argument("--no_cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no_micro", action="store_true", help="skip the upfirdn2d microbenchmark leg")
@@ -76,8 +78,9 @@ def make_trainer(args, device, world):
             mixed_precision=not args.fp32, channels_last=True, grad_accum=accum, hip_graph=not args.no_graph, graph_warmup=1,
         )
     else:
+        extra = {} if args.blur_size is None else {"blur_size": args.blur_size}
         cfg = TrainConfig(
-            model="stylegan2", img_size=args.img_size, gen_kwargs={"base_dim": args.base_dim}, disc_kwargs={"base_dim": args.base_dim},
+            model="stylegan2", img_size=args.img_size, gen_kwargs={"base_dim": args.base_dim, **extra}, disc_kwargs={"base_dim": args.base_dim, **extra},
             method="hinge", regularizer="r1", batch_size=args.global_batch, optimizer="Adam", optimizer_kwargs={"betas": [0.0, 0.9]},
             lr=2e-4, device="cuda", mixed_precision=not args.fp32, channels_last=True, grad_accum=accum,
             hip_graph=not args.no_graph, graph_warmup=1, bulk_noise=True,
@@ -482,7 +485,8 @@ def main():
             "config": {
                 "workload": (f"DCGAN WGAN-GP n_disc=5 train iteration, {args.img_size}x{args.img_size}, global batch {args.global_batch}, Adam, EMA"
                              if args.recipe == "dcgan" else
-                             f"StyleGAN2 hinge+R1 train step, {args.img_size}x{args.img_size}, base_dim {args.base_dim}, global batch {args.global_batch}, Adam, EMA"),
+                             f"StyleGAN2 hinge+R1 train step, {args.img_size}x{args.img_size}, base_dim {args.base_dim}, global batch {args.global_batch}, Adam, EMA"
+                             + ("" if args.blur_size is None else f", blur_size {args.blur_size} (NOT a BASELINE config)")),
                 "global_batch": args.global_batch,
                 "per_gpu_batch": args.global_batch // world,
                 "grad_accum": cfg.grad_accum,

@@ -1,5 +1,5 @@
 """Reads the s_memtime stamps of a diagnostic build of conv_wide_halo.hip (make -C gan_amd/csrc clean all
-EXTRA=-DGAN_HALO_STAMPS; rebuild without it afterwards): python tools/halo_stamps.py N Cin H W Cout"""
+EXTRA=-DGAN_HALO_STAMPS; rebuild without it afterwards): python tools/halo_stamps.py N Cin H W Cout [a|ar]   (a: mask stage, ar: mask + residual)"""
 import ctypes, os, sys
 import numpy as np
 import torch
@@ -11,8 +11,11 @@ n, cin, h, w, cout = map(int, sys.argv[1:6])
 dev = torch.device("cuda:0")
 x = torch.randn(n, cin, h, w, device=dev).bfloat16().contiguous(memory_format=torch.channels_last)
 wgt = torch.randn(cout, cin, 3, 3, device=dev) / (cin * 9) ** 0.5
+mode = sys.argv[6] if len(sys.argv) > 6 else ""
+aux = torch.randn(n, cout, h, w, device=dev).bfloat16().contiguous(memory_format=torch.channels_last) if mode else None
+res = torch.randn(n, cout, h, w, device=dev).bfloat16().contiguous(memory_format=torch.channels_last) if mode == "ar" else None
 for _ in range(20):
-    GF.raw_conv2d(x, wgt, 1, 1)
+    GF.raw_conv2d(x, wgt, 1, 1, aux=aux, aux_slope=0.2 if mode else 1.0, resid=res)
 torch.cuda.synchronize()
 lib = _lib.load()
 waves = 4 if (h % 16 == 0 and w % 16 == 0) else 8  # mirror of the launch selection
