@@ -78,7 +78,7 @@ def make_trainer(args, device, world):
             mixed_precision=not args.fp32, channels_last=True, grad_accum=accum, hip_graph=not args.no_graph, graph_warmup=1,
         )
     else:
-        extra = {} if args.blur_size is None else {"blur_size": args.blur_size}
+        extra = {} if getattr(args, "blur_size", None) is None else {"blur_size": args.blur_size}
         cfg = TrainConfig(
             model="stylegan2", img_size=args.img_size, gen_kwargs={"base_dim": args.base_dim, **extra}, disc_kwargs={"base_dim": args.base_dim, **extra},
             method="hinge", regularizer="r1", batch_size=args.global_batch, optimizer="Adam", optimizer_kwargs={"betas": [0.0, 0.9]},
