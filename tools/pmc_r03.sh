@@ -15,7 +15,7 @@ run() {  # name, counters, bench_op args...
 SQ1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY"
 SQ2="SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_WAVES"
 # PMC_SPECS: space-separated subset of the tags below (default: all)
-ALL=("wgrad:wgrad 256 128 32 32 128 3" "halo:fwd 256 128 32 32 128 3" "thin64:fwd 256 64 64 64 64 3" "thin16:fwd 256 16 256 256 16 3")
+ALL=("wgrad:wgrad 256 128 32 32 128 3" "halo:fwd 256 128 32 32 128 3" "thin64:fwd 256 64 64 64 64 3" "thin16:fwd 256 16 256 256 16 3" "thin16dp:fwd_pool 256 16 256 256 32 3" "thin32dp:fwd_pool 256 32 128 128 64 3")
 TAGS=""
 for spec in "${ALL[@]}"; do
   tag=${spec%%:*}
