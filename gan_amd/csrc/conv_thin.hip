@@ -5,7 +5,14 @@
 int gan_conv2d_fwd_thin(const void* x, const void* wt, void* y, const float* in_scale, const float* out_scale,
                         const float* bias, const void* noise, const float* noise_scale, float slope, int N, int H,
                         int W, int Cin, int up2, int Ho, int Wo, int Cout, int kh, int kw, int py, int px, int Kpad,
-                        const ConvFuse& fu, hipStream_t st) {
+                        const ConvFuse& fu_in, hipStream_t st) {
+    // a residual behind a plain (unmasked, unpooled) convolution -- the blur-enabled D block's merge on its shortcut
+    // convolution -- runs in the mask mode with the residual as its own mask operand at slope 1 (a mask of ones)
+    ConvFuse fu = fu_in;
+    if (fu.resid && !fu.aux && !fu.pool && !fu.sc_x && !fu.dot_out) {
+        fu.aux = fu.resid;
+        fu.aux_slope = 1.f;
+    }
     if (kh != kw || (kh != 1 && kh != 3)) return 0;
     if (py != (kh - 1) / 2 || px != py) return 0;
     if (Cin != 8 && Cin != 16 && Cin != 32 && Cin != 64) return 0;

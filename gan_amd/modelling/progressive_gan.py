@@ -68,8 +68,15 @@ class ProgressiveGanDiscriminatorBlock(nn.Module):
         act0, conv1, act1, conv2, down = self.layers
         conv_s = self.shortcut[1]
         if not isinstance(down, AvgPool2d):
-            # FIR down-sampling: activation + convolution + bias fused per launch, the two FIR passes, the residual pass
+            # FIR down-sampling: activation + convolution + bias fused per launch and the two FIR passes.  The FIR is linear
+            # and per channel, so the block's scale folds into conv2's parameters as it does below, and the merge
+            # shortcut + layers * scale (progressive_gan.py:54) rides as the residual of the shortcut's 1x1 convolution:
+            # no pass over the activations for the scale or the sum, forward or backward
             h = GF.conv_bias_act(x, conv1.weight, conv1.bias, conv1.padding[0], 1.0, act0.negative_slope)
+            if conv2.weight.dtype == torch.float32 and self.scale.dtype == torch.float32:
+                w2s, b2s = GF.scaled_conv_params(conv2.weight, conv2.bias, self.scale)
+                h = down(GF.conv_bias_act(h, w2s, b2s, conv2.padding[0], 1.0, act1.negative_slope))
+                return GF.conv_bias_act(self.shortcut[0](x), conv_s.weight, conv_s.bias, 0, 1.0, 1.0, False, h)
             h = down(GF.conv_bias_act(h, conv2.weight, conv2.bias, conv2.padding[0], 1.0, act1.negative_slope))
             s = conv_s(self.shortcut[0](x))
             return GF.affine_act(h, a=self.scale.reshape(-1), r=s)
