@@ -827,6 +827,37 @@ def test_conv2d_dgrad_mask_residual(dev, case):
     assert rel_err(got32, ref) < TOL32, rel_err(got32, ref)
 
 
+@pytest.mark.parametrize("case", [(2, 16, 64, 64, 32, 1), (2, 32, 40, 48, 64, 1), (3, 16, 64, 32, 16, 3), (2, 64, 32, 32, 64, 1), (2, 128, 16, 16, 256, 1)])
+def test_conv_bias_residual_plain(dev, case):
+    """conv(x, W) + b + resid with no mask and no pooling: the blur-enabled D block's merge on its shortcut convolution
+    (progressive_gan.py:52-54 with a FIR in place of AvgPool2d).  Thin shapes run in the mask mode with a mask of ones (the
+    residual is its own mask operand at slope 1 -- negative and zero residual values included), the others on the wide / generic
+    kernels' residual stage; first-order gradients of all four operands through ConvBiasActFn."""
+    import gan_amd.functional as GF
+
+    n, cin, h, w, cout, k = case
+    pad = (k - 1) // 2
+    torch.manual_seed(52)
+    x = torch.randn(n, cin, h, w).bfloat16()
+    resid = torch.randn(n, cout, h, w).bfloat16()
+    resid[0, :, :4] = 0.0
+    wgt = (torch.randn(cout, cin, k, k) / (cin * k * k) ** 0.5).bfloat16().float()
+    b = torch.randn(cout)
+    xr, wr, br, rr = (t.double().requires_grad_(True) for t in (x, wgt, b, resid))
+    ref = F.conv2d(xr, wr, br, padding=pad) + rr
+    cot = torch.randn_like(ref)
+    grads_ref = torch.autograd.grad((ref * cot).sum(), [xr, wr, br, rr])
+    xg = x.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    rg = resid.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    wg, bg = wgt.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+    got = GF.conv_bias_act(xg, wg, bg, pad, 1.0, 1.0, False, rg)
+    assert got.dtype == torch.bfloat16
+    assert rel_err(got, ref) < 4e-3, rel_err(got, ref)
+    grads = torch.autograd.grad((got.float() * cot.float().to(dev)).sum(), [xg, wg, bg, rg])
+    for g, gr in zip(grads, grads_ref):
+        assert rel_err(g, gr) < 6e-3, rel_err(g, gr)
+
+
 @pytest.mark.parametrize("in_dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("out_dtype", [torch.float32, torch.bfloat16])
 def test_pad_channels_kernel(dev, in_dtype, out_dtype):
