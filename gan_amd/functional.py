@@ -1388,6 +1388,129 @@ class DBlockInputFn(Function):
         return gx, gw1, gb1, gws, None, None, gbs
 
 
+_FUSE_DBLOCK = os.environ.get("GAN_AMD_FUSE_DBLOCK", "1") != "0"  # A/B runs: 0 = DBlockInputFn + ConvBiasActFn
+
+
+def _shortcut_fwd(x: Tensor, ws: Tensor, bs: Optional[Tensor], pool_in_conv: bool):
+    """AvgPool2d(2) -> conv1x1 (progressive_gan.py:52); thin layers: conv1x1 -> pool in one launch (the same linear map).
+    Returns (s, pooled x or None)."""
+    if pool_in_conv:
+        return raw_conv2d(x, ws, 0, 0, pool=True, bias=bs), None
+    xs = raw_upfirdn2d(x, _ones_taps(x, 0.25), 1, 2, 0, 0, x.shape[2] // 2, x.shape[3] // 2)
+    return raw_conv2d(xs, ws, 0, 0, bias=bs), xs
+
+
+class DBlockGradFn(Function):
+    """(gx, g_p1) of a whole discriminator block for the gradient gy of its output (progressive_gan.py:43-54, scale folded
+    into conv2: DBlockFn below):
+         g_p1 = m(p1) * dgrad3x3(PoolAdj(gy), W2s)        gx = m(x) * dgrad3x3(g_p1, W1) + PoolAdj(dgrad1x1(gy, Ws))
+    Forward: the kernels Conv2dDgradFn / DBlockInputGradFn run.  Backward -- R1's second-order pass, bilinear in (gy, W) for
+    fixed masks -- as ONE chain instead of the composition of those nodes' backwards:
+         z1 = m(x) * ggx;  z2 = m(p1) * conv(z1, W1) [the mask on the convolution's accumulators];
+         g_gy = Pool(conv(z2, W2s)) + conv1x1(Pool(ggx), Ws) [the shortcut term as the convolution's residual]
+    i.e. no mask pass between the two convolutions and no sum of two gradient tensors by the autograd engine (two
+    activation-sized passes per block and R1 step).  Weight gradients: wgrad(z1, g_p1), wgrad(Pool ggx, gy), wgrad(z2, gy)."""
+
+    @staticmethod
+    def forward(ctx, gy, x, p1, w1, ws, w2s, pad, slope0, slope1, pool_in_conv):
+        ctx.set_materialize_grads(False)
+        g_p1 = raw_conv2d_dgrad(gy, w2s, pad, pad, pooled=True, aux=p1, aux_slope=slope1)
+        gx = None
+        if pool_in_conv or (w1.shape[0] == 64 and w1.shape[1] == 64 and x.dtype == torch.bfloat16 and x.shape[3] >= 32):
+            gx = raw_dblock_input_grad(g_p1, w1, pad, x, slope0, gy, ws)
+        if gx is None:
+            if pool_in_conv:
+                gx_s = raw_conv2d_dgrad(gy, ws, 0, 0, pooled=True)
+            else:
+                gx_s = raw_upfirdn2d(raw_conv2d_dgrad(gy, ws, 0, 0), _ones_taps(x, 0.25), 2, 1, 1, 1, x.shape[2], x.shape[3])
+            gx = raw_conv2d_dgrad(g_p1, w1, pad, pad, aux=x, aux_slope=slope0, resid=gx_s)
+        ctx.save_for_backward(gy, x, p1, g_p1, w1, ws, w2s)
+        ctx.cfg = (pad, slope0, slope1, pool_in_conv)
+        return gx, g_p1
+
+    @staticmethod
+    def backward(ctx, ggx, gg_p1):
+        gy, x, p1, g_p1, w1, ws, w2s = ctx.saved_tensors
+        pad, slope0, slope1, pool_in_conv = ctx.cfg
+        need_gy, need_w1, need_ws, need_w2 = _need(ctx, 0), _need(ctx, 3), _need(ctx, 4), _need(ctx, 5)
+        if torch.is_grad_enabled():
+            # a third derivative is being recorded: the differentiable pieces (never in the train step)
+            g_gy = g_w1 = g_ws = g_w2 = None
+            u = gg_p1
+            if ggx is not None:
+                z1 = MaskMulFn.apply(ggx, x, slope0)
+                c1 = Conv2dFn.apply(z1, w1, pad, pad, 1.0, False)
+                u = c1 if u is None else c1 + u
+                g_w1 = Conv2dWgradFn.apply(z1, g_p1, 3, 3, pad, pad, 1.0, False).to(w1.dtype) if need_w1 else None
+                g_gy = Conv2dFn.apply(ggx, ws, 0, 0, 1.0, True).to(gy.dtype)
+                g_ws = Conv2dWgradFn.apply(ggx, gy, 1, 1, 0, 0, 1.0, True).to(ws.dtype) if need_ws else None
+            if u is not None:
+                z2 = MaskMulFn.apply(u, p1, slope1)
+                t = Conv2dFn.apply(z2, w2s, pad, pad, 1.0, True).to(gy.dtype)
+                g_gy = t if g_gy is None else g_gy + t
+                g_w2 = Conv2dWgradFn.apply(z2, gy, 3, 3, pad, pad, 1.0, True).to(w2s.dtype) if need_w2 else None
+            return g_gy, None, None, g_w1, g_ws, g_w2, None, None, None, None
+        z1 = raw_mask_scale(ggx, x, None, slope0) if ggx is not None else None
+        z2 = None
+        if need_gy or need_w2:
+            if z1 is not None and gg_p1 is None:
+                z2 = raw_conv2d(z1, w1, pad, pad, aux=p1, aux_slope=slope1)
+            elif z1 is not None:
+                z2 = raw_mask_scale(raw_conv2d(z1, w1, pad, pad) + gg_p1.to(z1.dtype), p1, None, slope1)
+            elif gg_p1 is not None:
+                z2 = raw_mask_scale(gg_p1, p1, None, slope1)
+        g_gy = None
+        if need_gy:
+            gs2 = _shortcut_fwd(ggx, ws, None, pool_in_conv)[0] if ggx is not None else None
+            g_gy = raw_conv2d(z2, w2s, pad, pad, pool=True, resid=gs2) if z2 is not None else gs2
+            if g_gy is not None:
+                g_gy = g_gy.to(gy.dtype)
+        g_w1 = _wgrad_for(w1, z1, g_p1, pad, pad, 1.0, False) if need_w1 and z1 is not None else None
+        g_ws = _wgrad_for(ws, ggx, gy, 0, 0, 1.0, True) if need_ws and ggx is not None else None
+        g_w2 = _wgrad_for(w2s, z2, gy, pad, pad, 1.0, True) if need_w2 and z2 is not None else None
+        return g_gy, None, None, g_w1, g_ws, g_w2, None, None, None, None
+
+
+class DBlockFn(Function):
+    """A discriminator block (progressive_gan.py:43-54) as ONE autograd node:
+         p1 = conv3x3(lrelu(x), W1) + b1;  s = conv1x1(AvgPool(x), Ws) + bs;  out = AvgPool(conv3x3(lrelu(p1), W2s)) + b2s + s
+    with (W2s, b2s) = scaled_conv_params(W2, b2, scale).  Three launches forward, as DBlockInputFn + ConvBiasActFn; the point
+    is the backward: the block's input gradient is DBlockGradFn, whose own backward (R1's second order) is one chain."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, ws, bs, w2s, b2s, slope0, slope1, pool_in_conv):
+        pad = (w1.shape[2] - 1) // 2
+        p1 = raw_conv2d(x, w1, pad, pad, bias=b1, in_slope=slope0)
+        s, xs = _shortcut_fwd(x, ws, bs, pool_in_conv)
+        out = raw_conv2d(p1, w2s, pad, pad, bias=b2s, in_slope=slope1, pool=True, resid=s)
+        ctx.save_for_backward(x, p1, xs, w1, b1, ws, bs, w2s, b2s)
+        ctx.cfg = (pad, slope0, slope1, pool_in_conv)
+        return out
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, p1, xs, w1, b1, ws, bs, w2s, b2s = ctx.saved_tensors
+        pad, slope0, slope1, pool_in_conv = ctx.cfg
+
+        def params(w, b, iw, ib, xin, g, py, x_slope, pooled):
+            want_b = b is not None and _need(ctx, ib)
+            if _need(ctx, iw) and want_b:
+                return _wgrad_and_bias_for(w, b, xin, g, py, py, x_slope, pooled)
+            return (_wgrad_for(w, xin, g, py, py, x_slope, pooled) if _need(ctx, iw) else None), (_bias_grad_for(b, g) if want_b else None)
+
+        gw2, gb2 = params(w2s, b2s, 5, 6, p1, gy, pad, slope1, True)
+        xs_in, pooled = (x, True) if pool_in_conv else (xs, False)
+        gws, gbs = params(ws, bs, 3, 4, xs_in, gy, 0, 1.0, pooled)
+        gx = g_p1 = None
+        need_c1 = _need(ctx, 1) or (b1 is not None and _need(ctx, 2))
+        if _need(ctx, 0):
+            gx, g_p1 = DBlockGradFn.apply(gy, x, p1, w1, ws, w2s, pad, slope0, slope1, pool_in_conv)
+        elif need_c1:
+            g_p1 = Conv2dDgradFn.apply(gy, w2s, pad, pad, p1, slope1, True)
+        gw1, gb1 = params(w1, b1, 1, 2, x, g_p1, pad, slope0, False) if need_c1 else (None, None)
+        return gx, gw1, gb1, gws, gbs, gw2, gb2, None, None, None
+
+
 class Conv2dWgradFn(Function):
     """gW = wgrad( leaky_relu?(x), PoolAdj?(gy) ) in fp32: the adjoint of Conv2dFn in W."""
 

@@ -82,6 +82,11 @@ class ProgressiveGanDiscriminatorBlock(nn.Module):
             return GF.affine_act(h, a=self.scale.reshape(-1), r=s)
         # act -> conv1 (+bias) and the shortcut (pool -> conv_s; for thin layers conv_s -> pool, the same linear
         # map, in one launch) share x: one autograd node, so their input gradients come out of one kernel
+        if GF._FUSE_DBLOCK and conv2.weight.dtype == torch.float32 and self.scale.dtype == torch.float32 and conv1.kernel_size == (3, 3):
+            # the whole block as one autograd node: its input gradient's own backward (R1's second order) is one chain
+            w2s, b2s = GF.scaled_conv_params(conv2.weight, conv2.bias, self.scale)
+            return GF.DBlockFn.apply(x, conv1.weight, conv1.bias, conv_s.weight, conv_s.bias, w2s, b2s, act0.negative_slope,
+                                     act1.negative_slope, conv_s.out_channels <= 64)
         h, s = GF.DBlockInputFn.apply(x, conv1.weight, conv1.bias, conv_s.weight, act0.negative_slope, conv_s.out_channels <= 64,
                                       conv_s.bias)
         # act -> conv2 -> pool (+ bias: avg_pool(z + b) = avg_pool(z) + b) in one launch, and the residual merge

@@ -1591,3 +1591,73 @@ def test_dblock_input_grad_fused(dev, case):
     gx_s = GF.raw_conv2d_dgrad(g_s, ws, 0, 0, pooled=True)
     two = GF.raw_conv2d_dgrad(g_p1, w1, 1, 1, aux=x, aux_slope=0.2, resid=gx_s)
     assert rel_err(got, two) < 1e-2
+
+
+@pytest.mark.parametrize("case", [(4, 16, 64, 64, torch.bfloat16), (4, 64, 32, 32, torch.bfloat16), (4, 128, 16, 16, torch.bfloat16),
+                                  (2, 16, 64, 64, torch.float32), (2, 128, 8, 8, torch.float32)])
+def test_dblock_one_node_vs_fp64_and_two_nodes(dev, case):
+    """DBlockFn / DBlockGradFn (the discriminator block as one autograd node whose input gradient's own backward -- R1's
+    second-order pass -- is one chain: mask on the convolution's accumulators, shortcut term as the residual) against the
+    block written in fp64 torch ops (progressive_gan.py:43-54) and against the two-node composition it replaces
+    (GAN_AMD_FUSE_DBLOCK=0): output, first-order gradients of x and of all seven parameters, and the gradients of
+    sum(dD/dx ^ 2) -- the R1 penalty's (losses.py:95-106) -- on thin (fused shortcut gradient), 64-channel and wide layers."""
+    import gan_amd.functional as GF
+    from gan_amd.modelling.progressive_gan import ProgressiveGanDiscriminatorBlock
+
+    n, c, h, w, dtype = case
+    torch.manual_seed(sum(case[:4]))
+    blk = ProgressiveGanDiscriminatorBlock(c, 2 * c).to(dev)
+    with torch.no_grad():
+        for p in blk.parameters():
+            p.copy_(torch.randn_like(p) * (0.5 if p.ndim == 1 else 1.0 / (p[0].numel() ** 0.5)))
+        blk.scale.copy_(torch.rand_like(blk.scale) + 0.5)
+    x0 = torch.randn(n, c, h, w, device=dev).to(dtype).contiguous(memory_format=torch.channels_last)
+    cot = torch.randn(n, 2 * c, h // 2, w // 2, device=dev)
+    params = list(blk.parameters())
+
+    def run(fused):
+        prev, GF._FUSE_DBLOCK = GF._FUSE_DBLOCK, fused
+        try:
+            x = x0.clone().requires_grad_(True)
+            out = blk(x)
+            first = torch.autograd.grad((out.float() * cot).sum(), [x] + params, retain_graph=True)
+            (gx,) = torch.autograd.grad((out.float() * cot).sum(), x, create_graph=True)
+            second = torch.autograd.grad(gx.float().square().sum(), params, allow_unused=True)
+            return out.detach(), first, second
+        finally:
+            GF._FUSE_DBLOCK = prev
+
+    def ref():
+        import torch.nn.functional as F
+
+        act0, conv1, act1, conv2, _ = blk.layers
+        conv_s = blk.shortcut[1]
+        ps = [p.detach().double().requires_grad_(True) for p in params]
+        # bf16: the kernels multiply bf16-rounded weights (value rounded, gradient passed straight through)
+        used = [q + (q.detach().bfloat16().double() - q.detach()) if (dtype == torch.bfloat16 and q.ndim == 4) else q for q in ps]
+        byname = dict(zip([k for k, _ in blk.named_parameters()], used))
+        x = x0.double().requires_grad_(True)
+        hh = F.conv2d(F.leaky_relu(x, 0.2), byname["layers.1.weight"], byname["layers.1.bias"], padding=1)
+        hh = F.avg_pool2d(F.conv2d(F.leaky_relu(hh, 0.2), byname["layers.3.weight"], byname["layers.3.bias"], padding=1), 2)
+        s = F.conv2d(F.avg_pool2d(x, 2), byname["shortcut.1.weight"], byname["shortcut.1.bias"])
+        out = s + hh * byname["scale"]
+        first = torch.autograd.grad((out * cot.double()).sum(), [x] + ps, retain_graph=True)
+        (gx,) = torch.autograd.grad((out * cot.double()).sum(), x, create_graph=True)
+        second = torch.autograd.grad(gx.square().sum(), ps, allow_unused=True)
+        return out.detach(), first, second
+
+    out1, f1, s1 = run(True)
+    out0, f0, s0 = run(False)
+    outr, fr, sr = ref()
+    tol = 3e-2 if dtype == torch.bfloat16 else 2e-5   # bf16: intermediates p1, g_p1, z2 are stored in bf16 (three roundings deep)
+    assert rel_err(out1, outr) < tol
+    for a, b, r in zip(f1, f0, fr):
+        assert rel_err(a, r) < tol, rel_err(a, r)
+        assert rel_err(a, b) < tol
+    for k, (a, b, r) in zip([k for k, _ in blk.named_parameters()], zip(s1, s0, sr)):
+        if r is None or float(r.abs().max()) == 0.0:  # the biases: dD/dx does not depend on them
+            assert a is None or float(a.abs().max()) == 0.0
+            assert b is None or float(b.abs().max()) == 0.0
+            continue
+        assert rel_err(a, r) < 2 * tol, (k, rel_err(a, r))
+        assert rel_err(a, b) < 2 * tol, (k, rel_err(a, b))
