@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GAN_AMD_LIB") or os.path.join(_HERE, "libgan_amd.so")
 
 GAN_F32, GAN_BF16 = 0, 1
-ABI_VERSION = 24
+ABI_VERSION = 25
 
 _SIGNATURES = {
     "gan_amd_version": (c_int, []),
@@ -56,6 +56,7 @@ _SIGNATURES = {
     "gan_scale_dot": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_int, c_void_p]),
     "gan_demod_fwd": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p]),
     "gan_demod_bwd": (c_int, [c_void_p] * 7 + [c_int] * 5 + [c_void_p]),
+    "gan_demod_multi": (c_int, [c_int, c_void_p, c_int, c_int64, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p]),
     "gan_pack_weight": (c_int, [c_void_p, c_int, c_void_p, c_int] + [c_int] * 7 + [c_void_p]),
     "gan_pad_channels": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int64, c_int64, c_void_p, c_int] + [c_int] * 5 + [c_void_p]),
     "gan_pack_weights_multi": (c_int, [c_void_p, c_int, c_int64, c_int, c_int, c_int, c_void_p]),

@@ -12,6 +12,6 @@ void gan_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-extern "C" int gan_amd_version(void) { return 24; }
+extern "C" int gan_amd_version(void) { return 25; }
 extern "C" const char* gan_amd_arch(void) { return "gfx950"; }
 extern "C" const char* gan_amd_last_error(void) { return g_err; }

@@ -1681,22 +1681,23 @@ struct DemodArgs {
     const float* wsq;
     float* out;
     int N, Cin, Cout, taps, accum;
+    int lds, ldd;  // row pitch of s / gs, and of g / dinv (the layer's columns of a matrix that holds every layer's: demod_multi_k)
 };
 
 template <int MODE>
-__global__ void __launch_bounds__(256) demod_mfma_k(const DemodArgs p) {
+__device__ __forceinline__ void demod_tile(const DemodArgs& p, const int bx, const int by) {
     __shared__ float red[4][256];
     __shared__ float tile[256];
     const int M = MODE == 2 ? p.Cout : p.N, Nn = MODE == 0 ? p.Cout : p.Cin, K = MODE == 0 ? p.Cin : (MODE == 1 ? p.Cout : p.N);
-    const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 16;
+    const int m0 = by * 16, n0 = bx * 16;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, g = lane >> 4;
     const int kq = ((((K + 3) >> 2) + 15) >> 4) << 4;  // K range of a wave, a multiple of 16
     const int kb = wave * kq, ke = min(K, kb + kq);
     const int m = m0 + i, n = n0 + i;
     const bool mok = m < M, nok = n < Nn;
     // rows that are contiguous in k can be read 16 bytes at a time
-    const bool vecA = MODE == 0 ? (p.Cin & 3) == 0 && ((uintptr_t)p.s & 15) == 0
-                                : (MODE == 1 ? (p.Cout & 3) == 0 && (((uintptr_t)p.g | (uintptr_t)p.dinv) & 15) == 0 : false);
+    const bool vecA = MODE == 0 ? (p.lds & 3) == 0 && ((uintptr_t)p.s & 15) == 0
+                                : (MODE == 1 ? (p.ldd & 3) == 0 && (((uintptr_t)p.g | (uintptr_t)p.dinv) & 15) == 0 : false);
     const bool vecB = MODE == 0 ? (p.Cin & 3) == 0 && ((uintptr_t)p.wsq & 15) == 0 : false;
     f32x4 c = {0.f, 0.f, 0.f, 0.f};
     for (int k0 = kb; k0 < ke; k0 += 128) {
@@ -1706,7 +1707,7 @@ __global__ void __launch_bounds__(256) demod_mfma_k(const DemodArgs p) {
             const int k = k0 + 16 * t + 4 * g;  // this lane's four k of group t
             // ---- A(m, k..k+3)
             if (MODE == 0 || MODE == 1) {
-                const int ld = MODE == 0 ? p.Cin : p.Cout;
+                const int ld = MODE == 0 ? p.lds : p.ldd;
                 const int64_t off = (int64_t)m * ld + k;
                 float x0[4] = {0.f, 0.f, 0.f, 0.f}, x1[4] = {1.f, 1.f, 1.f, 1.f};
                 if (mok && vecA && k + 3 < ke) {
@@ -1730,7 +1731,7 @@ __global__ void __launch_bounds__(256) demod_mfma_k(const DemodArgs p) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     float v = 0.f;
-                    if (mok && k + j < ke) v = demod_dq(p.g[(int64_t)(k + j) * p.Cout + m], p.dinv[(int64_t)(k + j) * p.Cout + m]);
+                    if (mok && k + j < ke) v = demod_dq(p.g[(int64_t)(k + j) * p.ldd + m], p.dinv[(int64_t)(k + j) * p.ldd + m]);
                     a[4 * t + j] = v;
                 }
             }
@@ -1749,7 +1750,7 @@ __global__ void __launch_bounds__(256) demod_mfma_k(const DemodArgs p) {
                 for (int j = 0; j < 4; ++j) {
                     float v = 0.f;
                     if (nok && k + j < ke) {
-                        v = (MODE == 1 ? p.wsq : p.s)[(int64_t)(k + j) * p.Cin + n];
+                        v = MODE == 1 ? p.wsq[(int64_t)(k + j) * p.Cin + n] : p.s[(int64_t)(k + j) * p.lds + n];
                         if (MODE == 2) v *= v;
                     }
                     b[4 * t + j] = v;
@@ -1766,9 +1767,9 @@ __global__ void __launch_bounds__(256) demod_mfma_k(const DemodArgs p) {
     const float v = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
     const int mo = m0 + row, no = n0 + col;
     if (MODE == 0) {
-        if (mo < M && no < Nn) p.out[(int64_t)mo * p.Cout + no] = 1.f / fmaxf(sqrtf(v), 1e-8f);
+        if (mo < M && no < Nn) p.out[(int64_t)mo * p.ldd + no] = 1.f / fmaxf(sqrtf(v), 1e-8f);
     } else if (MODE == 1) {
-        if (mo < M && no < Nn) p.out[(int64_t)mo * p.Cin + no] = 2.f * p.s[(int64_t)mo * p.Cin + no] * v;
+        if (mo < M && no < Nn) p.out[(int64_t)mo * p.lds + no] = 2.f * p.s[(int64_t)mo * p.lds + no] * v;
     } else {
         tile[tid] = v;
         __syncthreads();
@@ -1781,6 +1782,46 @@ __global__ void __launch_bounds__(256) demod_mfma_k(const DemodArgs p) {
             p.out[base + e] = p.accum ? p.out[base + e] + r : r;
         }
     }
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(256) demod_mfma_k(const DemodArgs p) {
+    demod_tile<MODE>(p, blockIdx.x, blockIdx.y);
+}
+
+// Every demodulating layer of a generator in ONE launch per product: the layers' styles are the column blocks of one
+// (N, sum Cin) matrix (they come out of one GEMM, stylegan2.py:30 for every layer at once) and their factors / factor
+// gradients the column blocks of one (N, sum Cout) matrix.  `table`: device memory, `count` rows of 10 int64:
+// [0] wsq, [1] w, [2] gw (MODE 2), [3] Cin, [4] Cout, [5] taps, [6] first style column, [7] first factor column,
+// [8] first workgroup of the row, [9] accumulate into gw.  (13 layers: 26 + 26 launches of 5-14 us per iteration, the same
+// at any batch, become 2 + 2.)
+constexpr int DEMOD_ROW = 10;
+template <int MODE>
+__global__ void __launch_bounds__(256) demod_multi_k(const long long* __restrict__ table, int count, const float* __restrict__ s_all, int lds,
+                                                     const float* __restrict__ g_all, const float* __restrict__ dinv_all, int ldd,
+                                                     float* __restrict__ out_all, int N) {
+    __shared__ int which;
+    for (int i = threadIdx.x; i < count; i += 256) {
+        const long long b0 = table[i * DEMOD_ROW + 8];
+        const long long b1 = i + 1 < count ? table[(i + 1) * DEMOD_ROW + 8] : (long long)gridDim.x;
+        if ((long long)blockIdx.x >= b0 && (long long)blockIdx.x < b1) which = i;
+    }
+    __syncthreads();
+    const long long* __restrict__ d = table + which * DEMOD_ROW;
+    DemodArgs p;
+    p.Cin = (int)d[3]; p.Cout = (int)d[4]; p.taps = (int)d[5]; p.N = N; p.accum = (int)d[9];
+    p.lds = lds; p.ldd = ldd;
+    const int soff = (int)d[6], doff = (int)d[7];
+    p.wsq = reinterpret_cast<const float*>(d[0]);
+    p.w = reinterpret_cast<const float*>(d[1]);
+    p.s = s_all + soff;
+    p.g = g_all ? g_all + doff : nullptr;
+    p.dinv = dinv_all ? dinv_all + doff : nullptr;
+    p.out = MODE == 0 ? out_all + doff : (MODE == 1 ? out_all + soff : reinterpret_cast<float*>(d[2]));
+    const int Nn = MODE == 0 ? p.Cout : p.Cin;
+    const int tx = (Nn + 15) / 16;
+    const int local = (int)((long long)blockIdx.x - d[8]);
+    demod_tile<MODE>(p, local % tx, local / tx);
 }
 
 template <int MODE>
@@ -1798,7 +1839,7 @@ extern "C" int gan_demod_fwd(const float* s, const float* w, float* wsq, float* 
         const int64_t ne = (int64_t)Cout * Cin;
         hipLaunchKernelGGL(wsq_k, dim3((unsigned)ceil_div64(ne, TPB)), dim3(TPB), 0, st, w, wsq, ne, taps);
     }
-    DemodArgs a{nullptr, nullptr, s, nullptr, wsq, dinv, N, Cin, Cout, taps, 0};
+    DemodArgs a{nullptr, nullptr, s, nullptr, wsq, dinv, N, Cin, Cout, taps, 0, Cin, Cout};
     demod_launch<0>(a, st);
     GAN_CHECK_LAUNCH("demod_fwd");
     return GAN_OK;
@@ -1810,13 +1851,29 @@ extern "C" int gan_demod_bwd(const float* g, const float* dinv, const float* s, 
     GAN_CHECK_ARG(N > 0 && Cin > 0 && Cout > 0 && taps > 0 && (N + 15) / 16 <= 65535 && (Cout + 15) / 16 <= 65535, "demod_bwd: bad shape");
     hipStream_t st = (hipStream_t)stream;
     if (gs) {
-        DemodArgs a{g, dinv, s, w, wsq, gs, N, Cin, Cout, taps, 0};
+        DemodArgs a{g, dinv, s, w, wsq, gs, N, Cin, Cout, taps, 0, Cin, Cout};
         demod_launch<1>(a, st);
     }
     if (gw) {
-        DemodArgs a{g, dinv, s, w, wsq, gw, N, Cin, Cout, taps, gw_accumulate};
+        DemodArgs a{g, dinv, s, w, wsq, gw, N, Cin, Cout, taps, gw_accumulate, Cin, Cout};
         demod_launch<2>(a, st);
     }
     GAN_CHECK_LAUNCH("demod_bwd");
+    return GAN_OK;
+}
+
+// mode 0: dinv_all (N, ldd) from s_all (N, lds); 1: gs_all (N, lds) from (g_all, dinv_all, s_all); 2: every row's gw.
+// `blocks`: the table's total workgroup count for this mode (the caller laid out column [8] for it).
+extern "C" int gan_demod_multi(int mode, const void* table, int count, int64_t blocks, const float* s_all, int lds, const float* g_all,
+                               const float* dinv_all, int ldd, float* out_all, int N, gan_stream_t stream) {
+    GAN_CHECK_ARG(mode >= 0 && mode <= 2 && table && count > 0 && blocks > 0 && blocks < (1LL << 31), "demod_multi: bad arguments");
+    GAN_CHECK_ARG(s_all && N > 0 && lds > 0 && ldd > 0, "demod_multi: bad shape");
+    GAN_CHECK_ARG(mode == 0 ? out_all != nullptr : (g_all && dinv_all && (mode == 2 || out_all)), "demod_multi: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const long long* t = (const long long*)table;
+    if (mode == 0) hipLaunchKernelGGL(demod_multi_k<0>, dim3((unsigned)blocks), dim3(256), 0, st, t, count, s_all, lds, g_all, dinv_all, ldd, out_all, N);
+    else if (mode == 1) hipLaunchKernelGGL(demod_multi_k<1>, dim3((unsigned)blocks), dim3(256), 0, st, t, count, s_all, lds, g_all, dinv_all, ldd, out_all, N);
+    else hipLaunchKernelGGL(demod_multi_k<2>, dim3((unsigned)blocks), dim3(256), 0, st, t, count, s_all, lds, g_all, dinv_all, ldd, out_all, N);
+    GAN_CHECK_LAUNCH("demod_multi");
     return GAN_OK;
 }

@@ -672,6 +672,8 @@ def prepack_weights(weights) -> bool:
             _PACK_CACHE[(id(w), dt, mt, True)] = (ref, ver, img_t)
         if wsq is not None:
             _WSQ_CACHE[id(w)] = (ref, ver, wsq)
+    if _DEMOD_WANTS and not torch.cuda.is_current_stream_capturing():
+        _build_wanted_demod_tables()
     return True
 
 
@@ -1641,6 +1643,18 @@ def mapping_network(net: torch.nn.Sequential, z: Tensor) -> Tensor:
 _SPLIT_OFFSETS: dict = {}
 
 
+def _split_offsets(device, sizes):
+    """(device int32 tensor, list) of the column offsets of SplitColsFn for these sizes; uploaded once per size tuple."""
+    key = (device, tuple(sizes))
+    off = _SPLIT_OFFSETS.get(key)
+    if off is None:
+        acc = [0]
+        for c in sizes:
+            acc.append(acc[-1] + c)
+        off = _SPLIT_OFFSETS[key] = (torch.tensor(acc, dtype=torch.int32, device=device), acc)
+    return off
+
+
 class SplitColsFn(Function):
     """(N, T) fp32 -> one contiguous (N, C_l) tensor per layer (views of one buffer), one launch; backward: one torch.cat."""
 
@@ -1649,13 +1663,7 @@ class SplitColsFn(Function):
         require_gpu(x)
         lib = _lib.load()
         n, t = x.shape
-        key = (x.device, tuple(sizes))
-        off = _SPLIT_OFFSETS.get(key)
-        if off is None:
-            acc = [0]
-            for c in sizes:
-                acc.append(acc[-1] + c)
-            off = _SPLIT_OFFSETS[key] = (torch.tensor(acc, dtype=torch.int32, device=x.device), acc)
+        off = _split_offsets(x.device, sizes)
         x = x.detach().to(torch.float32).contiguous()
         out = torch.empty((n * t,), dtype=torch.float32, device=x.device)
         check(lib.gan_split_cols(ptr(x), ptr(out), ptr(off[0]), len(sizes), n, t, 0, stream_of(x)), "gan_split_cols")
@@ -1957,6 +1965,152 @@ class DemodFn(Function):
         check(lib.gan_demod_bwd(ptr(g), ptr(dinv), ptr(s32), ptr(w32), ptr(wsq), ptr(gs), ptr(gw), int(slot is not None), n, cin, cout, taps,
                                 stream_of(g)), "gan_demod_bwd")
         return (gs.to(s.dtype) if gs is not None else None), (gw.to(weight.dtype) if gw is not None and slot is None else None)
+
+
+# ---- every demodulating layer of a generator at once (gan_demod_multi) --------------------------------------------
+_DEMOD_TABLES: dict = {}
+_DEMOD_WANTS: dict = {}
+
+
+def _build_wanted_demod_tables() -> None:
+    for key, (refs, soffs, n) in list(_DEMOD_WANTS.items()):
+        ws = [r() for r in refs]
+        if any(w is None for w in ws) or _demod_tables(ws, soffs, n) is not None:
+            del _DEMOD_WANTS[key]
+_FUSE_DEMOD = os.environ.get("GAN_AMD_FUSE_DEMOD", "1") != "0"  # A/B runs: 0 = one DemodFn per layer
+
+
+def _demod_tables(weights, soffs, n: int):
+    """The three launch tables (factor, style gradient, weight gradient) of gan_demod_multi for these weights at batch n, or
+    None when they cannot be had: a weight without current tap sums from prepack_weights, or tables that would have to be
+    uploaded while the stream is being captured.  The weight-gradient table points at the parameters' CURRENT .grad buffers
+    (the flat arena's slices: stable); the backward uses it only if the pass may add in place and they are still those."""
+    wsqs, slots = [], []
+    for w in weights:
+        hit = _WSQ_CACHE.get(id(w))
+        if hit is None or hit[0]() is not w or hit[1] != (w._version, w.data_ptr()) or w.dtype != torch.float32 or not w.is_contiguous():
+            return None
+        wsqs.append(hit[2])
+        g = w.grad if isinstance(w, torch.nn.Parameter) else None
+        slots.append(g if g is not None and g.dtype == torch.float32 and g.is_contiguous() and g.shape == w.shape and g.is_cuda else None)
+    key = (n, tuple(soffs), tuple(w.data_ptr() for w in weights), tuple(q.data_ptr() for q in wsqs),
+           tuple(g.data_ptr() if g is not None else 0 for g in slots))
+    hit = _DEMOD_TABLES.get(key)
+    if hit is not None:
+        return hit
+    if torch.cuda.is_current_stream_capturing():
+        return None
+    if len(_DEMOD_TABLES) > 64:
+        _DEMOD_TABLES.clear()
+    dev = weights[0].device
+    doffs, acc = [], 0
+    for w in weights:
+        doffs.append(acc)
+        acc += w.shape[0]
+    tabs = []
+    for mode in range(3):
+        rows, blocks = [], 0
+        for w, q, g, so, do in zip(weights, wsqs, slots, soffs, doffs):
+            cout, cin, kh, kw = w.shape
+            m_, n_ = ((n, cout), (n, cin), (cout, cin))[mode]
+            rows.append([q.data_ptr(), w.data_ptr(), g.data_ptr() if g is not None else 0, cin, cout, kh * kw, so, do, blocks, 1])
+            blocks += -(-n_ // 16) * -(-m_ // 16)
+        tabs.append((torch.tensor(rows, dtype=torch.int64, device=dev), blocks))
+    _split_offsets(dev, tuple(w.shape[0] for w in weights))  # (demod_all splits the factors: uploaded here, outside any capture)
+    out = _DEMOD_TABLES[key] = {"tabs": tabs, "doffs": doffs, "ldd": acc, "wsqs": list(wsqs),
+                                "slot_ptrs": [g.data_ptr() if g is not None else 0 for g in slots]}
+    return out
+
+
+class DemodAllFn(Function):
+    """dinv_all (N, sum Cout_l) = the demodulation factors (DemodFn) of every demodulating layer l of a generator, from the
+    matrix s_all (N, sum Cin over all modulated layers) that holds every layer's style (stylegan2.py:30: one GEMM, all layers
+    see the same w) -- layer l's style starts at column soffs[l].  One launch forward, two backward (gan_demod_multi) instead
+    of one / two per layer: these are (N, C)-sized products whose cost is their launch, the same at any batch.  Weight
+    gradients go straight into the parameters' buffers (direct_param_grads); under create_graph the backward is DemodFn's
+    formula on column slices."""
+
+    @staticmethod
+    def forward(ctx, s_all, soffs, tables, *weights):
+        lib = _lib.load()
+        s32 = s_all.detach().float().contiguous()
+        n, lds = s32.shape
+        dinv_all = torch.empty((n, tables["ldd"]), dtype=torch.float32, device=s32.device)
+        tab, blocks = tables["tabs"][0]
+        check(lib.gan_demod_multi(0, ptr(tab), len(weights), blocks, ptr(s32), lds, None, None, tables["ldd"], ptr(dinv_all), n, stream_of(s32)),
+              "gan_demod_multi")
+        ctx.save_for_backward(s_all, dinv_all, *weights)
+        ctx.soffs, ctx.tables = tuple(soffs), tables
+        return dinv_all
+
+    @staticmethod
+    def backward(ctx, g_all):
+        s_all, dinv_all, *weights = ctx.saved_tensors
+        soffs, tables = ctx.soffs, ctx.tables
+        doffs = tables["doffs"]
+        n, lds = s_all.shape
+        need_w = [_need(ctx, 3 + i) for i in range(len(weights))]
+        if torch.is_grad_enabled():
+            # recorded again: DemodFn's formula layer by layer, on tensor ops
+            gs_all = torch.zeros_like(s_all, dtype=torch.float32) if _need(ctx, 0) else None
+            gws = []
+            for i, (w, so, do) in enumerate(zip(weights, soffs, doffs)):
+                cout, cin = w.shape[0], w.shape[1]
+                sf, wf, g = s_all[:, so:so + cin].float(), w.float(), g_all[:, do:do + cout].float()
+                wsq_t = wf.square().sum(dim=(2, 3))
+                d = (sf.square() @ wsq_t.t()).rsqrt()
+                dq = torch.where(d < 1e8, -0.5 * d * d * d * g, torch.zeros_like(d))
+                if gs_all is not None:
+                    gs_all = gs_all + F.pad(2.0 * sf * (dq @ wsq_t), (so, lds - so - cin))
+                gws.append((2.0 * wf * (dq.t() @ sf.square())[:, :, None, None]).to(w.dtype) if need_w[i] else None)
+            return (gs_all.to(s_all.dtype) if gs_all is not None else None), None, None, *gws
+        lib = _lib.load()
+        s32 = s_all.detach().float().contiguous()
+        g32 = g_all.detach().float().contiguous()
+        ldd = tables["ldd"]
+        gs_all = None
+        if _need(ctx, 0):
+            gs_all = torch.zeros((n, lds), dtype=torch.float32, device=s32.device)  # (the columns of layers that do not demodulate stay 0)
+            tab, blocks = tables["tabs"][1]
+            check(lib.gan_demod_multi(1, ptr(tab), len(weights), blocks, ptr(s32), lds, ptr(g32), ptr(dinv_all), ldd, ptr(gs_all), n, stream_of(s32)),
+                  "gan_demod_multi")
+            gs_all = gs_all.to(s_all.dtype)
+        gws = [None] * len(weights)
+        if any(need_w):
+            live = [grad_slot(w) for w in weights]
+            if all(need_w) and all(g is not None and g.data_ptr() == q for g, q in zip(live, tables["slot_ptrs"])):
+                tab, blocks = tables["tabs"][2]
+                check(lib.gan_demod_multi(2, ptr(tab), len(weights), blocks, ptr(s32), lds, ptr(g32), ptr(dinv_all), ldd, None, n, stream_of(s32)),
+                      "gan_demod_multi")
+            else:  # (no in-place accumulation in this pass: one launch per layer, gradients handed to autograd)
+                for i, (w, so, do, wsq, slot) in enumerate(zip(weights, soffs, doffs, tables["wsqs"], live)):
+                    if not need_w[i]:
+                        continue
+                    cout, cin, kh, kw = w.shape
+                    gw = slot if slot is not None else torch.empty_like(w, dtype=torch.float32)
+                    gl, dl, sl = g32[:, do:do + cout].contiguous(), dinv_all[:, do:do + cout].contiguous(), s32[:, so:so + cin].contiguous()
+                    check(lib.gan_demod_bwd(ptr(gl), ptr(dl), ptr(sl), ptr(w.detach()), ptr(wsq), None, ptr(gw), int(slot is not None), n, cin, cout,
+                                            kh * kw, stream_of(s32)), "gan_demod_bwd")
+                    gws[i] = None if slot is not None else gw.to(w.dtype)
+        return gs_all, None, None, *gws
+
+
+def demod_all(s_all: Tensor, soffs, weights):
+    """The demodulation factor of every weight in `weights` (layer l's style = columns soffs[l] .. of s_all) as a tuple of
+    contiguous (N, Cout_l) tensors from one launch, or None when the tables cannot be had (see _demod_tables): the caller
+    then evaluates DemodFn layer by layer."""
+    if not _FUSE_DEMOD or not weights or not s_all.is_cuda:
+        return None
+    tables = _demod_tables(weights, soffs, s_all.shape[0])
+    if tables is None:
+        # remembered: prepack_weights() builds the tables after the next optimizer step, when the tap sums exist and the
+        # stream is not being captured (a trainer captures its second iteration: the first must leave them behind)
+        if len(_DEMOD_WANTS) > 16:
+            _DEMOD_WANTS.clear()
+        _DEMOD_WANTS[(tuple(id(w) for w in weights), s_all.shape[0])] = ([weakref.ref(w) for w in weights], tuple(soffs), s_all.shape[0])
+        return None
+    dinv_all = DemodAllFn.apply(s_all, tuple(soffs), tables, *weights)
+    return SplitColsFn.apply(dinv_all, tuple(w.shape[0] for w in weights))
 
 
 class MbstdFn(Function):

@@ -171,6 +171,7 @@ class ModulatedConv2d(nn.Conv2d):
         self.demodulation = demodulation
 
     _styles = None  # (N, Cin) set by StyleGan2Generator.forward: every layer's A(w) + 1 from ONE GEMM
+    _dinv = None    # (N, Cout) set there too when all layers' demodulation factors came from one launch
 
     def style_and_demod(self, w: Tensor):
         """s = A(w) + 1 (stylegan2.py:30) and the demodulation factor of F.normalize(dim=(2,3,4),
@@ -179,8 +180,10 @@ class ModulatedConv2d(nn.Conv2d):
             s, self._styles = self._styles, None
             if s is None:
                 s = F.linear(w.float(), self.style_weight.weight, self.style_weight.bias) + 1  # (N, Cin)
-            dinv = None
-            if self.demodulation:
+            dinv, self._dinv = self._dinv, None
+            if not self.demodulation:
+                dinv = None
+            elif dinv is None:
                 dinv = GF.DemodFn.apply(s, self.weight)  # (N, Cout); raises on CPU tensors like every op here
         return s, dinv
 
@@ -295,6 +298,18 @@ class StyleGan2Generator(nn.Module):
             parts = GF.SplitColsFn.apply(s_all, tuple(m.in_channels for m in mods))  # one launch, not a copy per layer
             for m, s in zip(mods, parts):
                 m._styles = s
+                m._dinv = None
+            # the demodulation factors of all layers from one launch too (else: DemodFn layer by layer, style_and_demod)
+            dem, soffs, acc = [], [], 0
+            for m in mods:
+                if m.demodulation:
+                    dem.append(m)
+                    soffs.append(acc)
+                acc += m.in_channels
+            dinvs = GF.demod_all(s_all, soffs, [m.weight for m in dem])
+            if dinvs is not None:
+                for m, d in zip(dem, dinvs):
+                    m._dinv = d
 
     def forward(self, z: Tensor) -> Tensor:
         # mapping network: LayerNorm + 8 x (128x128 Linear + LeakyReLU) on (N,128), fp32 -- one launch (mapping.hip)

@@ -117,6 +117,17 @@ int gan_demod_fwd(const float* s, const float* w, float* wsq, float* dinv, int N
                   gan_stream_t stream);
 int gan_demod_bwd(const float* g, const float* dinv, const float* s, const float* w, const float* wsq, float* gs,
                   float* gw, int gw_accumulate, int N, int Cin, int Cout, int taps, gan_stream_t stream);
+/* The same three products for EVERY demodulating layer of a generator in one launch each (the reference evaluates
+ * modelling/stylegan2.py:30-33 layer by layer; all layers see the same w, so their styles are the column blocks of one
+ * (N, lds) matrix s_all and their factors / factor gradients the column blocks of one (N, ldd) matrix):
+ *   mode 0: out_all = dinv_all (N, ldd);  mode 1: out_all = gs_all (N, lds) from g_all, dinv_all (N, ldd) and s_all;
+ *   mode 2: every row's gw (+)= from the same.
+ * `table`: device memory, `count` rows of 10 int64: [0] wsq, [1] w, [2] gw, [3] Cin, [4] Cout, [5] taps, [6] the layer's
+ * first column in s_all, [7] its first column in dinv_all / g_all, [8] its first workgroup in THIS mode's launch
+ * (ceil(Nn/16) * ceil(M/16) workgroups per row; (M, Nn) = (N, Cout), (N, Cin), (Cout, Cin) for modes 0, 1, 2),
+ * [9] accumulate into gw.  `blocks`: the launch's workgroup count.  Columns [6], [7] multiples of 4. */
+int gan_demod_multi(int mode, const void* table, int count, int64_t blocks, const float* s_all, int lds, const float* g_all,
+                    const float* dinv_all, int ldd, float* out_all, int N, gan_stream_t stream);
 
 /* ---- implicit-GEMM convolution (MFMA) ----------------------------------------------------
  * replaces ModulatedConv2d.forward / batched_conv2d   modelling/stylegan2.py:18-36

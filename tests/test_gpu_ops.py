@@ -1661,3 +1661,54 @@ def test_dblock_one_node_vs_fp64_and_two_nodes(dev, case):
             continue
         assert rel_err(a, r) < 2 * tol, (k, rel_err(a, r))
         assert rel_err(a, b) < 2 * tol, (k, rel_err(a, b))
+
+
+def test_demod_all_layers_one_launch(dev):
+    """gan_demod_multi (DemodAllFn / demod_all): the demodulation factors of several layers from the matrix that holds every
+    layer's style -- a layer that does not demodulate sits between them, as the generator's to-RGB layers do -- against
+    DemodFn layer by layer (stylegan2.py:30-33): factors, style gradient (zero in the other layer's columns), weight gradients
+    handed to autograd, and weight gradients added straight into the parameters' buffers (direct_param_grads)."""
+    import gan_amd.functional as GF
+
+    torch.manual_seed(77)
+    n = 6
+    shapes = [(32, 16, 3, 3), (24, 32, 3, 3), (40, 24, 1, 1)]   # (Cout, Cin, kh, kw)
+    cins = [16, 8, 32, 24]                                      # the style matrix: layer 0, a layer that does not demodulate, layers 1, 2
+    soffs = [0, 24, 56]
+    ws = [torch.nn.Parameter(torch.randn(*s, device=dev) / (s[1] * s[2] * s[3]) ** 0.5) for s in shapes]
+    s_all = (torch.randn(n, sum(cins), device=dev) * 0.5 + 1.0).requires_grad_(True)
+    cots = [torch.randn(n, s[0], device=dev) for s in shapes]
+
+    def per_layer():
+        s = s_all.detach().clone().requires_grad_(True)
+        outs = [GF.DemodFn.apply(s[:, o:o + w.shape[1]], w) for w, o in zip(ws, soffs)]
+        grads = torch.autograd.grad(sum((d * c).sum() for d, c in zip(outs, cots)), [s] + ws)
+        return [d.detach() for d in outs], grads
+
+    want, gwant = per_layer()          # (also registers the weights' tap sums with prepack_weights)
+    for w in ws:
+        w.grad = torch.zeros_like(w)
+    assert GF.prepack_weights(ws) or True
+    got = GF.demod_all(s_all, soffs, ws)
+    if got is None:                    # tables are built by prepack_weights once a request is on record
+        GF.prepack_weights(ws)
+        GF._build_wanted_demod_tables()
+        got = GF.demod_all(s_all, soffs, ws)
+    assert got is not None, "gan_demod_multi path not taken"
+    for a, b in zip(got, want):
+        assert a.is_contiguous() and rel_err(a, b) < 1e-5
+    grads = torch.autograd.grad(sum((d * c).sum() for d, c in zip(got, cots)), [s_all] + ws)
+    for a, b in zip(grads, gwant):
+        assert rel_err(a, b) < 1e-5, rel_err(a, b)
+    assert float(grads[0][:, 16:24].abs().max()) == 0.0
+    # in place: the weight gradients land in .grad, autograd gets None
+    for w in ws:
+        w.grad.zero_()
+    got = GF.demod_all(s_all, soffs, ws)
+    with GF.direct_param_grads():
+        (gs,) = torch.autograd.grad(sum((d * c).sum() for d, c in zip(got, cots)), [s_all], allow_unused=True)
+        got2 = GF.demod_all(s_all, soffs, ws)
+        sum((d * c).sum() for d, c in zip(got2, cots)).backward(inputs=[s_all] + ws)
+    assert rel_err(gs, gwant[0]) < 1e-5
+    for w, b in zip(ws, gwant[1:]):
+        assert rel_err(w.grad, b) < 1e-5, rel_err(w.grad, b)
