@@ -400,6 +400,78 @@ __global__ void __launch_bounds__(256) conv_full_k(const T* __restrict__ x, cons
     }
 }
 
+// ---- 1x1 convolution into <= 4 channels on maps too small for the thin kernel: the generator's to-RGB layers at 4x4 .. 32x32
+// (stylegan2.py:64, 512 .. 128 channels -> 3).  The implicit-GEMM kernel gives such a layer M / 256 workgroups (two at 4x4,
+// batch 32) that each walk all of K: 15-32 us whatever the batch, four layers, two generator passes per iteration.  Here a
+// wave owns four pixels of one image: a lane holds 8 channels of the (style-scaled) weights in registers, reads 16 bytes
+// of each pixel, and the wave reduces the 4 x <= 4 sums.
+__global__ void __launch_bounds__(256) conv1x1_narrow_k(const bf16* __restrict__ x, const bf16* __restrict__ wt, bf16* __restrict__ y,
+                                                        const float* __restrict__ in_scale, const float* __restrict__ bias, int64_t M, int HW,
+                                                        int Cin, int Cout, int Kpad, float gain, float slope) {
+    // four pixels of one image per wave (HW % 4 == 0), their loads, the weights' and the style's all issued before the first use
+    constexpr int PPW = 4;
+    const int lane = threadIdx.x & 63;
+    const int64_t p0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * PPW;
+    if (p0 >= M) return;
+    const int c0 = lane * 8;
+    const bool act = c0 < Cin;
+    const int n = (int)(p0 / HW);
+    float xv[PPW][8], w[4][8], sc[8];
+#pragma unroll
+    for (int q = 0; q < PPW; ++q) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xv[q][j] = 0.f;
+        if (act && p0 + q < M) load_f<bf16, 8>(x + (p0 + q) * Cin + c0, xv[q]);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) w[r][j] = 0.f;
+        if (act && r < Cout) load_f<bf16, 8>(wt + (int64_t)r * Kpad + c0, w[r]);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sc[j] = 1.f;
+    if (in_scale && act) {
+        const float4 a = *reinterpret_cast<const float4*>(in_scale + (int64_t)n * Cin + c0);
+        const float4 b = *reinterpret_cast<const float4*>(in_scale + (int64_t)n * Cin + c0 + 4);
+        sc[0] = a.x; sc[1] = a.y; sc[2] = a.z; sc[3] = a.w; sc[4] = b.x; sc[5] = b.y; sc[6] = b.z; sc[7] = b.w;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) w[r][j] *= sc[j];
+    float acc[PPW][4];
+#pragma unroll
+    for (int q = 0; q < PPW; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float a = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a = fmaf(xv[q][j], w[r][j], a);
+            acc[q][r] = a;
+        }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+        for (int q = 0; q < PPW; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[q][r] += __shfl_xor(acc[q][r], off);
+    // lane 4q + r stores channel r of pixel q
+    const int q = lane >> 2, r = lane & 3;
+    if (lane < 4 * PPW && r < Cout && p0 + q < M) {
+        float v = 0.f;
+#pragma unroll
+        for (int qq = 0; qq < PPW; ++qq)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr)
+                if (qq == q && rr == r) v = acc[qq][rr];
+        v *= gain;
+        if (bias) v += bias[r];
+        v = v > 0.f ? v : v * slope;
+        y[(p0 + q) * Cout + r] = (bf16)v;
+    }
+}
+
 static int conv2d_fwd_impl(const void* x, const void* wt, void* y, const float* in_scale, const float* out_scale,
                            const float* bias, const void* noise, const float* noise_scale, float slope, int N,
                            int H, int W, int Cin, int up2, int Ho, int Wo, int Cout, int kh, int kw, int py, int px,
@@ -455,6 +527,18 @@ static int conv2d_fwd_impl(const void* x, const void* wt, void* y, const float* 
     if (dot_out || sc_x) {
         gan_set_error("conv2d_fwd_dot / conv2d_fwd_short: shape not served (ask gan_conv2d_fwd_dot_supported / _short_supported first)");
         return GAN_ERR_ARG;
+    }
+    if (kh == 1 && kw == 1 && py == 0 && px == 0 && !up2 && Cout <= 4 && Cin <= 512 && !out_scale && !noise && !pool && !aux && !resid &&
+        in_slope == 1.f && ((uintptr_t)in_scale % 16) == 0 && (Ho * Wo) % 4 == 0) {
+        static const bool narrow = !(getenv("GAN_AMD_NARROW1X1") && atoi(getenv("GAN_AMD_NARROW1X1")) == 0);  // 0: the implicit-GEMM kernel (A/B runs)
+        if (narrow) {
+            const int HW = Ho * Wo;
+            const int64_t waves = (a.M + 3) / 4;
+            hipLaunchKernelGGL(conv1x1_narrow_k, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, (const bf16*)x, (const bf16*)wt, (bf16*)y,
+                               in_scale, bias, a.M, HW, Cin, Cout, Kpad, gain, slope);
+            GAN_CHECK_LAUNCH("conv2d_fwd(narrow 1x1)");
+            return GAN_OK;
+        }
     }
     if (!in_scale) {
         const int wide = gan_conv2d_fwd_wide(x, wt, y, out_scale, bias, noise, noise_scale, slope, N, H, W, Cin, up2, Ho, Wo,

@@ -1712,3 +1712,26 @@ def test_demod_all_layers_one_launch(dev):
     assert rel_err(gs, gwant[0]) < 1e-5
     for w, b in zip(ws, gwant[1:]):
         assert rel_err(w.grad, b) < 1e-5, rel_err(w.grad, b)
+
+
+@pytest.mark.parametrize("case", [(3, 512, 4, 4, 3), (2, 256, 16, 16, 3), (5, 128, 8, 8, 4), (2, 40, 4, 4, 1), (2, 512, 2, 2, 3)])
+def test_conv1x1_into_few_channels_small_maps(dev, case):
+    """The generator's to-RGB layers below 32 x 32 (stylegan2.py:64: 1x1, style-modulated, bias, no demodulation) on
+    conv1x1_narrow_k -- four pixels per wave -- and on the implicit-GEMM kernel they used to run on (GAN_AMD_NARROW1X1=0 is read
+    once per process, so the comparison is against fp64 of the bf16-rounded operands): channel counts that leave lanes idle,
+    one to four output channels, a map whose pixel count is a multiple of 4 only."""
+    import gan_amd.functional as GF
+
+    n, c, h, w, co = case
+    torch.manual_seed(sum(case))
+    x = torch.randn(n, c, h, w).bfloat16()
+    wgt = (torch.randn(co, c, 1, 1) / c ** 0.5)
+    s = torch.rand(n, c) + 0.5
+    b = torch.randn(co)
+    got = GF.raw_conv2d(x.to(dev).contiguous(memory_format=torch.channels_last), wgt.to(dev), 0, 0, in_scale=s.to(dev), bias=b.to(dev))
+    ref = F.conv2d(x.double() * s.double()[:, :, None, None], wgt.bfloat16().double(), b.double())
+    assert got.shape == ref.shape and got.dtype == torch.bfloat16
+    assert rel_err(got, ref) < 6e-3, rel_err(got, ref)
+    got2 = GF.raw_conv2d(x.to(dev).contiguous(memory_format=torch.channels_last), wgt.to(dev), 0, 0, slope=0.2)
+    ref2 = F.leaky_relu(F.conv2d(x.double(), wgt.bfloat16().double()), 0.2)
+    assert rel_err(got2, ref2) < 6e-3, rel_err(got2, ref2)
