@@ -1475,16 +1475,19 @@ class DBlockGradFn(Function):
 
 class DBlockFn(Function):
     """A discriminator block (progressive_gan.py:43-54) as ONE autograd node:
-         p1 = conv3x3(lrelu(x), W1) + b1;  s = conv1x1(AvgPool(x), Ws) + bs;  out = AvgPool(conv3x3(lrelu(p1), W2s)) + b2s + s
+         p1 = lrelu(conv3x3(lrelu(x), W1) + b1);  s = conv1x1(AvgPool(x), Ws) + bs;  out = AvgPool(conv3x3(p1, W2s)) + b2s + s
     with (W2s, b2s) = scaled_conv_params(W2, b2, scale).  Three launches forward, as DBlockInputFn + ConvBiasActFn; the point
     is the backward: the block's input gradient is DBlockGradFn, whose own backward (R1's second order) is one chain."""
 
     @staticmethod
     def forward(ctx, x, w1, b1, ws, bs, w2s, b2s, slope0, slope1, pool_in_conv):
         pad = (w1.shape[2] - 1) // 2
-        p1 = raw_conv2d(x, w1, pad, pad, bias=b1, in_slope=slope0)
+        # p1 is stored ACTIVATED (conv1's output stage applies the second LeakyReLU): conv2 is its only consumer, the masks
+        # m(p1) read signs only, and the wide kernels -- which have no input-side stage -- need no activation pass in front of
+        # conv2 (12 activation-sized launches per iteration)
+        p1 = raw_conv2d(x, w1, pad, pad, bias=b1, in_slope=slope0, slope=slope1)
         s, xs = _shortcut_fwd(x, ws, bs, pool_in_conv)
-        out = raw_conv2d(p1, w2s, pad, pad, bias=b2s, in_slope=slope1, pool=True, resid=s)
+        out = raw_conv2d(p1, w2s, pad, pad, bias=b2s, pool=True, resid=s)
         ctx.save_for_backward(x, p1, xs, w1, b1, ws, bs, w2s, b2s)
         ctx.cfg = (pad, slope0, slope1, pool_in_conv)
         return out
@@ -1500,7 +1503,7 @@ class DBlockFn(Function):
                 return _wgrad_and_bias_for(w, b, xin, g, py, py, x_slope, pooled)
             return (_wgrad_for(w, xin, g, py, py, x_slope, pooled) if _need(ctx, iw) else None), (_bias_grad_for(b, g) if want_b else None)
 
-        gw2, gb2 = params(w2s, b2s, 5, 6, p1, gy, pad, slope1, True)
+        gw2, gb2 = params(w2s, b2s, 5, 6, p1, gy, pad, 1.0, True)
         xs_in, pooled = (x, True) if pool_in_conv else (xs, False)
         gws, gbs = params(ws, bs, 3, 4, xs_in, gy, 0, 1.0, pooled)
         gx = g_p1 = None
